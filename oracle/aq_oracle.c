@@ -1,0 +1,362 @@
+/*
+ * CPU oracle for the adaptive-quantisation hot path.  TEST INFRASTRUCTURE ONLY:
+ * nothing under quantized-cnn_amd/ may link, load or call this file; it is the
+ * checker used by tests/, by __graft_entry__.smoke() and by bench.py's
+ * cpu_baseline leg.
+ *
+ * It restates, in plain C, the algorithm of the reference's quantized layers:
+ *   weight synthesis   adp_qtz_fan.py:563-571  (fix:668-673, hint:665-670,
+ *                      hard codes: adp_qtz_fan_test.py:304-305)
+ *   regulariser        adp_qtz_fan.py:737-754  (sum of W^2 per layer)
+ *   9-tap convolution  adp_qtz_fan.py:574-601
+ *   linear             adp_qtz_fan.py:633-648
+ * and the gradients autograd derives from them (adp_qtz_fan.py:290).
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * here against the .npz fixtures under tests/golden, which tests/golden/make_golden.py produced
+ * by running the reference's own classes.
+ *
+ * Row-local arithmetic (one weight = one row of L primary coefficients) is a
+ * fully specified sequence of IEEE-754 binary32 operations (fmaf, *, +, /,
+ * sqrtf, rintf, ldexpf, no contraction, no reassociation), so that the HIP
+ * kernels, which perform the same sequence, can be compared BIT FOR BIT on W,
+ * on the codes and on dp_c.  The sequence ("8x4 layout"):
+ *   - a row is padded with zeros to LP = 4*G elements, G = 8, 16 or 32 lanes
+ *     (the smallest with LP >= L); lane j owns elements 4j..4j+3;
+ *   - a per-lane partial is a left-to-right chain over the lane's 4 elements;
+ *   - lane partials are combined by an xor butterfly (masks 1,2,4,..,G/2),
+ *     i.e. a balanced binary tree in natural lane order;
+ *   - exp() is aqo_expf below (Cody-Waite reduction + degree-5 polynomial).
+ * Sums that run ACROSS rows (sum W^2, dq_level, conv accumulations) are kept
+ * in double here; the kernels reduce them in fp32 in a fixed, documented order
+ * and are compared within a tolerance.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define AQO_MAX_LP 128
+
+/* Hot entry points are compiled twice (hardware-FMA clone + baseline clone) and
+ * picked at load time, so one .so runs on any x86-64 host; fmaf() is exact in
+ * both, only its speed differs. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define AQO_CLONES __attribute__((target_clones("arch=haswell", "default")))
+#else
+#define AQO_CLONES
+#endif
+#define AQO_INLINE static inline __attribute__((always_inline))
+
+/* ------------------------------------------------------------------ exp --- */
+/* exp(x) for binary32, ~1 ulp: x = q*ln2 + s, |s| <= ln2/2, two-constant
+ * reduction, polynomial in s, scale by 2^q.  Same operation sequence as the
+ * device function aq_expf in quantized-cnn_amd/csrc/aq_arith.h. */
+AQO_INLINE float expf_spec(float x)
+{
+    const float R_LN2 = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2U = 0.693145751953125f;
+    const float L2L = 1.428606765330187045e-06f;
+    float qf = rintf(x * R_LN2);
+    float s = fmaf(qf, -L2U, x);
+    s = fmaf(qf, -L2L, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    float r;
+    if (x > 88.72283905206835f) r = INFINITY;
+    else if (x < -104.0f) r = 0.0f;
+    else if (x != x) r = x + x;
+    else r = ldexpf(u, (int)qf);
+    return r;
+}
+
+float aqo_expf(float x) { return expf_spec(x); }
+
+AQO_INLINE int lanes_for(int L) { return L <= 32 ? 8 : (L <= 64 ? 16 : 32); }
+
+AQO_INLINE float tree(float *v, int G)
+{
+    float t[32];
+    for (int m = 1; m < G; m <<= 1) {
+        for (int j = 0; j < G; ++j) t[j] = v[j] + v[j ^ m];
+        memcpy(v, t, sizeof(float) * G);
+    }
+    return v[0];
+}
+
+/* key used for the arg-max over s_c: NaN is maximal (torch.max semantics,
+ * adp_qtz_fan_test.py:304), every NaN compares equal, ties -> lowest index. */
+AQO_INLINE uint32_t amax_key(float s)
+{
+    uint32_t b;
+    memcpy(&b, &s, 4);
+    return (s != s) ? 0x7fc00000u : (b & 0x7fffffffu);
+}
+
+typedef struct {
+    float pn[AQO_MAX_LP], s[AQO_MAX_LP];
+    float rn, W;
+    int idx;
+} row_state;
+
+/* forward of one row; shared by forward and backward */
+AQO_INLINE void row_forward(const float *p, const float *q, int L, float beta, row_state *st)
+{
+    const int G = lanes_for(L), LP = 4 * G;
+    float pp[AQO_MAX_LP], qq[AQO_MAX_LP], e[AQO_MAX_LP], v[32];
+    for (int i = 0; i < LP; ++i) { pp[i] = i < L ? p[i] : 0.0f; qq[i] = i < L ? q[i] : 0.0f; }
+    for (int j = 0; j < G; ++j) {
+        const float *a = pp + 4 * j;
+        float t = a[0] * a[0];
+        t = fmaf(a[1], a[1], t); t = fmaf(a[2], a[2], t); t = fmaf(a[3], a[3], t);
+        v[j] = t;
+    }
+    const float ss = tree(v, G);
+    const float rn = 1.0f / sqrtf(ss);
+    for (int i = 0; i < LP; ++i) {
+        st->pn[i] = pp[i] * rn;
+        e[i] = i < L ? expf_spec(beta * st->pn[i]) : 0.0f;
+    }
+    for (int j = 0; j < G; ++j) v[j] = ((e[4 * j] + e[4 * j + 1]) + e[4 * j + 2]) + e[4 * j + 3];
+    const float den = tree(v, G);
+    const float rden = 1.0f / den;
+    for (int i = 0; i < LP; ++i) st->s[i] = e[i] * rden;
+    for (int j = 0; j < G; ++j) {
+        const float *s = st->s + 4 * j, *b = qq + 4 * j;
+        float t = s[0] * b[0];
+        t = fmaf(s[1], b[1], t); t = fmaf(s[2], b[2], t); t = fmaf(s[3], b[3], t);
+        v[j] = t;
+    }
+    st->W = tree(v, G);
+    st->rn = rn;
+    uint32_t best = amax_key(st->s[0]);
+    int bi = 0;
+    for (int i = 1; i < L; ++i) {
+        uint32_t k = amax_key(st->s[i]);
+        if (k > best) { best = k; bi = i; }
+    }
+    st->idx = bi;
+}
+
+/* W[r] (soft), idx[r], W_hard[r] = q[idx[r]], *sumsq = sum_r W[r]^2 (double).
+ * Any output pointer may be NULL. */
+AQO_CLONES void aqo_synth_fwd(const float *p_c, const float *q, int64_t rows, int L, float beta,
+                   float *W, int32_t *idx, float *W_hard, double *sumsq)
+{
+    double acc = 0.0;
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        row_state st;
+        row_forward(p_c + r * (int64_t)L, q, L, beta, &st);
+        if (W) W[r] = st.W;
+        if (idx) idx[r] = st.idx;
+        if (W_hard) W_hard[r] = q[st.idx];
+        acc += (double)st.W * (double)st.W;
+    }
+    if (sumsq) *sumsq = acc;
+}
+
+/* dp_c[r,:] and dq[:] for upstream dW[r]; wd = 2*l2_reg*(d loss / d reg) folds the
+ * regulariser's gradient in: g = dW + wd*W.  dq accumulates in double. */
+AQO_CLONES void aqo_synth_bwd(const float *p_c, const float *q, int64_t rows, int L, float beta,
+                   const float *dW, float wd, float *dp_c, double *dq)
+{
+    const int G = lanes_for(L), LP = 4 * G;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    double *part = (double *)calloc((size_t)nt * AQO_MAX_LP, sizeof(double));
+#pragma omp parallel
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double *mine = part + (size_t)tid * AQO_MAX_LP;
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < rows; ++r) {
+            row_state st;
+            float qq[AQO_MAX_LP], gpn[AQO_MAX_LP], v[32];
+            row_forward(p_c + r * (int64_t)L, q, L, beta, &st);
+            for (int i = 0; i < LP; ++i) qq[i] = i < L ? q[i] : 0.0f;
+            const float g = fmaf(wd, st.W, dW ? dW[r] : 0.0f);
+            const float dot = g * st.W;
+            for (int i = 0; i < LP; ++i) {
+                const float gs = g * qq[i];
+                const float gz = st.s[i] * (gs - dot);
+                gpn[i] = beta * gz;
+            }
+            for (int j = 0; j < G; ++j) {
+                const float *a = st.pn + 4 * j, *b = gpn + 4 * j;
+                float t = a[0] * b[0];
+                t = fmaf(a[1], b[1], t); t = fmaf(a[2], b[2], t); t = fmaf(a[3], b[3], t);
+                v[j] = t;
+            }
+            const float dpn = tree(v, G);
+            for (int i = 0; i < L; ++i) {
+                if (dp_c) dp_c[r * (int64_t)L + i] = fmaf(-st.pn[i], dpn, gpn[i]) * st.rn;
+                mine[i] += (double)st.s[i] * (double)g;
+            }
+        }
+    }
+    if (dq)
+        for (int i = 0; i < L; ++i) {
+            double a = 0.0;
+            for (int t = 0; t < nt; ++t) a += part[(size_t)t * AQO_MAX_LP + i];
+            dq[i] = a;
+        }
+    free(part);
+}
+
+/* ------------------------------------------------------------ convolution --- */
+/* y[n,co,oy,ox] = sum_{ci,dy,dx} W[co,ci,dy,dx] * x[n,ci,oy*s+dy-pad,ox*s+dx-pad]
+ * (cross-correlation, zero padding, no bias), accumulated tap by tap in the
+ * reference's loop order: width tap outer, height tap inner (adp_qtz_fan.py:581-599). */
+void aqo_conv_fwd(const float *x, const float *W, int N, int Cin, int H, int Wd, int Cout,
+                  int ks, int stride, int pad, float *y)
+{
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (Wd + 2 * pad - ks) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int co = 0; co < Cout; ++co) {
+            float *yo = y + ((int64_t)n * Cout + co) * Ho * Wo;
+            for (int i = 0; i < Ho * Wo; ++i) yo[i] = 0.0f;
+            for (int dx = 0; dx < ks; ++dx)
+                for (int dy = 0; dy < ks; ++dy)
+                    for (int oy = 0; oy < Ho; ++oy) {
+                        const int iy = oy * stride + dy - pad;
+                        if (iy < 0 || iy >= H) continue;
+                        for (int ox = 0; ox < Wo; ++ox) {
+                            const int ix = ox * stride + dx - pad;
+                            if (ix < 0 || ix >= Wd) continue;
+                            double a = 0.0;
+                            for (int ci = 0; ci < Cin; ++ci)
+                                a += (double)W[(((int64_t)co * Cin + ci) * ks + dy) * ks + dx] *
+                                     (double)x[(((int64_t)n * Cin + ci) * H + iy) * Wd + ix];
+                            yo[oy * Wo + ox] += (float)a;
+                        }
+                    }
+        }
+}
+
+/* dx = d loss / d x  given dy */
+void aqo_conv_dgrad(const float *dy, const float *W, int N, int Cin, int H, int Wd, int Cout,
+                    int ks, int stride, int pad, float *dx)
+{
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (Wd + 2 * pad - ks) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int iy = 0; iy < H; ++iy)
+                for (int ix = 0; ix < Wd; ++ix) {
+                    double a = 0.0;
+                    for (int ky = 0; ky < ks; ++ky) {
+                        const int ty = iy + pad - ky;
+                        if (ty < 0 || ty % stride) continue;
+                        const int oy = ty / stride;
+                        if (oy >= Ho) continue;
+                        for (int kx = 0; kx < ks; ++kx) {
+                            const int tx = ix + pad - kx;
+                            if (tx < 0 || tx % stride) continue;
+                            const int ox = tx / stride;
+                            if (ox >= Wo) continue;
+                            for (int co = 0; co < Cout; ++co)
+                                a += (double)W[(((int64_t)co * Cin + ci) * ks + ky) * ks + kx] *
+                                     (double)dy[(((int64_t)n * Cout + co) * Ho + oy) * Wo + ox];
+                        }
+                    }
+                    dx[(((int64_t)n * Cin + ci) * H + iy) * Wd + ix] = (float)a;
+                }
+}
+
+/* dW = d loss / d W  given dy */
+void aqo_conv_wgrad(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout,
+                    int ks, int stride, int pad, float *dW)
+{
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (Wd + 2 * pad - ks) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx) {
+                    double a = 0.0;
+                    for (int n = 0; n < N; ++n)
+                        for (int oy = 0; oy < Ho; ++oy) {
+                            const int iy = oy * stride + ky - pad;
+                            if (iy < 0 || iy >= H) continue;
+                            const float *xr = x + (((int64_t)n * Cin + ci) * H + iy) * Wd;
+                            const float *gr = dy + (((int64_t)n * Cout + co) * Ho + oy) * Wo;
+                            for (int ox = 0; ox < Wo; ++ox) {
+                                const int ix = ox * stride + kx - pad;
+                                if (ix < 0 || ix >= Wd) continue;
+                                a += (double)xr[ix] * (double)gr[ox];
+                            }
+                        }
+                    dW[(((int64_t)co * Cin + ci) * ks + ky) * ks + kx] = (float)a;
+                }
+}
+
+/* ----------------------------------------------------------------- linear --- */
+/* y[n,o] = sum_i x[n,i] * W[i,o] + b[o]; W is (in, out) as in adp_qtz_fan.py:609,647 */
+void aqo_linear_fwd(const float *x, const float *W, const float *b, int N, int In, int Out, float *y)
+{
+    for (int n = 0; n < N; ++n)
+        for (int o = 0; o < Out; ++o) {
+            double a = 0.0;
+            for (int i = 0; i < In; ++i) a += (double)x[n * In + i] * (double)W[i * Out + o];
+            y[n * Out + o] = (float)a + (b ? b[o] : 0.0f);
+        }
+}
+
+void aqo_linear_bwd(const float *x, const float *W, const float *dy, int N, int In, int Out,
+                    float *dx, float *dW, float *db)
+{
+    if (dx)
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < In; ++i) {
+                double a = 0.0;
+                for (int o = 0; o < Out; ++o) a += (double)dy[n * Out + o] * (double)W[i * Out + o];
+                dx[n * In + i] = (float)a;
+            }
+    if (dW)
+        for (int i = 0; i < In; ++i)
+            for (int o = 0; o < Out; ++o) {
+                double a = 0.0;
+                for (int n = 0; n < N; ++n) a += (double)x[n * In + i] * (double)dy[n * Out + o];
+                dW[i * Out + o] = (float)a;
+            }
+    if (db)
+        for (int o = 0; o < Out; ++o) {
+            double a = 0.0;
+            for (int n = 0; n < N; ++n) a += (double)dy[n * Out + o];
+            db[o] = (float)a;
+        }
+}
+
+int aqo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void aqo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

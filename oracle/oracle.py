@@ -1,0 +1,190 @@
+"""ctypes front end of the CPU oracle (libaq_oracle.so, built from aq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from the product package.  All functions take
+and return numpy arrays (float32 unless stated).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libaq_oracle.so")
+    src = os.path.join(_HERE, "aq_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libaq_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libaq_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        fp, ip, dp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        L.aqo_expf.argtypes, L.aqo_expf.restype = [C.c_float], C.c_float
+        L.aqo_synth_fwd.argtypes = [fp, fp, C.c_int64, C.c_int, C.c_float, fp, ip, fp, dp]
+        L.aqo_synth_bwd.argtypes = [fp, fp, C.c_int64, C.c_int, C.c_float, fp, C.c_float, fp, dp]
+        conv = [fp, fp] + [C.c_int] * 8 + [fp]
+        L.aqo_conv_fwd.argtypes = conv
+        L.aqo_conv_dgrad.argtypes = conv
+        L.aqo_conv_wgrad.argtypes = conv
+        L.aqo_linear_fwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp]
+        L.aqo_linear_bwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp]
+        L.aqo_num_threads.restype = C.c_int
+        L.aqo_set_num_threads.argtypes = [C.c_int]
+        for f in ("aqo_synth_fwd", "aqo_synth_bwd", "aqo_conv_fwd", "aqo_conv_dgrad", "aqo_conv_wgrad",
+                  "aqo_linear_fwd", "aqo_linear_bwd", "aqo_set_num_threads"):
+            getattr(L, f).restype = None
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def num_threads():
+    return lib().aqo_num_threads()
+
+
+def set_num_threads(n):
+    lib().aqo_set_num_threads(int(n))
+
+
+def expf(x):
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    L = lib()
+    flat_in, flat_out = x.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = L.aqo_expf(float(flat_in[i]))
+    return out
+
+
+def synth_fwd(p_c, q, beta, want_idx=True):
+    """p_c (..., L), q (L,) -> dict(W (...), idx int32 (...), W_hard (...), sumsq float64)."""
+    p, pp = _f(p_c)
+    qa, qp = _f(q)
+    L = p.shape[-1]
+    rows = p.size // L
+    W = np.empty(p.shape[:-1], np.float32)
+    Wh = np.empty(p.shape[:-1], np.float32)
+    idx = np.empty(p.shape[:-1], np.int32)
+    ss = C.c_double(0.0)
+    lib().aqo_synth_fwd(pp, qp, rows, L, float(beta), W.ctypes.data_as(C.POINTER(C.c_float)),
+                        idx.ctypes.data_as(C.POINTER(C.c_int32)) if want_idx else None,
+                        Wh.ctypes.data_as(C.POINTER(C.c_float)) if want_idx else None, C.byref(ss))
+    return {"W": W, "idx": idx, "W_hard": Wh, "sumsq": ss.value}
+
+
+def synth_bwd(p_c, q, beta, dW, wd=0.0, want_dp=True):
+    """-> dp_c (same shape as p_c), dq float64 (L,).  g = dW + wd*W per weight."""
+    p, pp = _f(p_c)
+    qa, qp = _f(q)
+    L = p.shape[-1]
+    rows = p.size // L
+    if dW is None:
+        g, gp = None, None
+    else:
+        g, gp = _f(dW)
+        assert g.size == rows
+    dp = np.empty_like(p) if want_dp else None
+    dq = np.zeros(L, np.float64)
+    lib().aqo_synth_bwd(pp, qp, rows, L, float(beta), gp, float(wd),
+                        dp.ctypes.data_as(C.POINTER(C.c_float)) if want_dp else None,
+                        dq.ctypes.data_as(C.POINTER(C.c_double)))
+    return dp, dq
+
+
+def _out_hw(H, ks, stride, pad):
+    return (H + 2 * pad - ks) // stride + 1
+
+
+def conv_fwd(x, W, stride=1, pad=1):
+    xa, xp = _f(x)
+    wa, wp = _f(W)
+    N, Cin, H, Wd = xa.shape
+    Cout, _, ks, _ = wa.shape
+    y = np.empty((N, Cout, _out_hw(H, ks, stride, pad), _out_hw(Wd, ks, stride, pad)), np.float32)
+    lib().aqo_conv_fwd(xp, wp, N, Cin, H, Wd, Cout, ks, stride, pad, y.ctypes.data_as(C.POINTER(C.c_float)))
+    return y
+
+
+def conv_dgrad(dy, W, x_shape, stride=1, pad=1):
+    ga, gp = _f(dy)
+    wa, wp = _f(W)
+    N, Cin, H, Wd = x_shape
+    Cout, _, ks, _ = wa.shape
+    dx = np.empty(x_shape, np.float32)
+    lib().aqo_conv_dgrad(gp, wp, N, Cin, H, Wd, Cout, ks, stride, pad, dx.ctypes.data_as(C.POINTER(C.c_float)))
+    return dx
+
+
+def conv_wgrad(x, dy, ks=3, stride=1, pad=1):
+    xa, xp = _f(x)
+    ga, gp = _f(dy)
+    N, Cin, H, Wd = xa.shape
+    Cout = ga.shape[1]
+    dW = np.empty((Cout, Cin, ks, ks), np.float32)
+    lib().aqo_conv_wgrad(xp, gp, N, Cin, H, Wd, Cout, ks, stride, pad, dW.ctypes.data_as(C.POINTER(C.c_float)))
+    return dW
+
+
+def linear_fwd(x, W, b):
+    xa, xp = _f(x)
+    wa, wp = _f(W)
+    ba, bp = _f(b)
+    N, In = xa.shape
+    Out = wa.shape[1]
+    y = np.empty((N, Out), np.float32)
+    lib().aqo_linear_fwd(xp, wp, bp, N, In, Out, y.ctypes.data_as(C.POINTER(C.c_float)))
+    return y
+
+
+def linear_bwd(x, W, dy):
+    xa, xp = _f(x)
+    wa, wp = _f(W)
+    ga, gp = _f(dy)
+    N, In = xa.shape
+    Out = wa.shape[1]
+    dx, dW, db = np.empty((N, In), np.float32), np.empty((In, Out), np.float32), np.empty(Out, np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().aqo_linear_bwd(xp, wp, gp, N, In, Out, dx.ctypes.data_as(fp), dW.ctypes.data_as(fp), db.ctypes.data_as(fp))
+    return dx, dW, db
+
+
+# ---- level initialisers (host logic of the reference, restated) -------------------------------
+
+def levels_fix(s, num_level, liar=True):
+    """adp_qtz_fix.py:661-665: [-2^t .. descending magnitude], 0, [2^t ..]; num_level-1 entries."""
+    import math
+    t2 = math.floor(math.log(s, 2)) if liar else round(math.log(s, 2))
+    t3 = np.arange(t2 - num_level / 2 + 2, t2 + 1)
+    pos = (2.0 ** t3).astype(np.float32)
+    return np.concatenate([np.sort(-pos), np.zeros(1, np.float32), pos]).astype(np.float32)
+
+
+def levels_hint(s, num_level):
+    """adp_qtz_hint.py:657-662: num_level entries, no zero."""
+    import math
+    t2 = math.floor(math.log(s, 2))
+    t3 = np.arange(t2 - num_level / 2 + 1, t2 + 1)
+    pos = (2.0 ** t3).astype(np.float32)
+    return np.concatenate([np.sort(-pos), pos]).astype(np.float32)
+
+
+def fan_bound(fan_in):
+    """adp_qtz_fan.py:551-560: q_level ~ U(-b, b)."""
+    import math
+    gain = math.sqrt(2.0 / (1 + 5.0))
+    return math.sqrt(3.0) * gain / math.sqrt(fan_in)

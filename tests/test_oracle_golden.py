@@ -1,0 +1,162 @@
+"""The CPU oracle against the fixtures produced by running the reference (tests/golden/make_golden.py).
+
+Tolerances (fp32 path, reference computes the same quantities in a different operation order):
+  W, W_hard, y            : |a-b| <= 1e-6*max|q| + 2e-6*|b|       (weights are sums of +-levels: cancellation)
+  dp_c                    : |a-b| <= 3e-5*max|dp_c row| + 1e-5*max|dp_c fixture|
+  dq, sum W^2             : rel 1e-5
+  codes (idx)             : exact, except rows the fixture itself flags as decided by fp32 rounding
+                            inside the reference ("rounding_tie"), which are reported and must be rare.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def _cases(g):
+    return range(int(g["ncase"]))
+
+
+def test_synth_forward_matches_reference(golden):
+    g = golden("synth")
+    n_rows = n_flag = 0
+    for c in _cases(g):
+        k = "c%02d_" % c
+        variant, init, beta, L = g[k + "meta"][0], g[k + "meta"][1], float(g[k + "meta"][2]), int(g[k + "meta"][3])
+        p, q = g[k + "p_c"], g[k + "q"]
+        assert p.shape[1] == L == q.shape[0]
+        assert L == (31 if variant == "fix" else 32)
+        r = O.synth_fwd(p, q, beta)
+        names = list(g[k + "special"])
+        nan_row = names.index("all_zero_nan")
+        ok = np.ones(p.shape[0], bool)
+        ok[nan_row] = False
+        qmax = np.abs(q).max()
+        assert np.all(np.abs(r["W"][ok] - g[k + "W"][ok]) <= 1e-6 * qmax + 2e-6 * np.abs(g[k + "W"][ok])), (c, variant)
+        # all-zero row: 0/0 -> NaN weight in the reference and here
+        assert np.isnan(g[k + "W"][nan_row]) and np.isnan(r["W"][nan_row])
+        flag = g[k + "rounding_tie"]
+        same = r["idx"] == g[k + "idx"]
+        assert np.all(same | flag), (c, np.nonzero(~same)[0])
+        n_rows += p.shape[0]
+        n_flag += int(flag.sum())
+        # hard weights: exactly the level the code selects
+        assert np.array_equal(r["W_hard"][same], g[k + "W_hard"][same])
+        # designed rows
+        tie = names.index("exact_tie_of_max_first_index_wins")
+        assert r["idx"][tie] == 3 == g[k + "idx"][tie]
+        assert r["idx"][names.index("all_equal")] == 0 == g[k + "idx"][names.index("all_equal")]
+        assert r["idx"][nan_row] == 0 == g[k + "idx"][nan_row]
+        assert r["idx"][names.index("one_hot_last")] == L - 1
+        # regulariser value: l2_reg * sum W^2 (NaN row poisons it in the reference too)
+        assert np.isnan(g[k + "reg"]) and np.isnan(r["sumsq"])
+        ss = float(np.sum(r["W"][ok].astype(np.float64) ** 2))
+        ss_ref = float(np.sum(g[k + "W"][ok].astype(np.float64) ** 2))
+        assert abs(ss - ss_ref) <= 1e-5 * ss_ref
+    assert n_flag <= max(1, n_rows // 1000)
+
+
+def test_synth_backward_matches_reference(golden):
+    g = golden("synth")
+    for c in _cases(g):
+        k = "c%02d_" % c
+        variant, beta = g[k + "meta"][0], float(g[k + "meta"][2])
+        p, q, dW = g[k + "p_c"], g[k + "q"], g[k + "dW"]
+        names = list(g[k + "special"])
+        ok = np.ones(p.shape[0], bool)
+        ok[names.index("all_zero_nan")] = False
+        # rows whose norm under/overflows in fp32 lose all precision in the reference as well
+        soft = ok.copy()
+        soft[names.index("tiny_magnitude")] = False
+        soft[names.index("huge_magnitude")] = False
+        dp, dq = O.synth_bwd(p[ok], q, beta, dW[ok], 0.0)
+        ref = g[k + "dp_c"][ok]
+        tol = 3e-5 * np.abs(ref).max(axis=1, keepdims=True) + 1e-5 * np.abs(ref[soft[ok]]).max()
+        assert np.all((np.abs(dp - ref) <= tol)[soft[ok]]), (c, variant)
+        assert np.all(np.isnan(g[k + "dp_c"][~ok]))
+        if variant == "fix":
+            assert g[k + "dq"].size == 0  # levels are frozen in the reference (requires_grad=False)
+        # regulariser-only gradient: g = 2*l2_reg*W
+        dpr, dqr = O.synth_bwd(p[ok], q, beta, None, 2 * 5e-4)
+        ref = g[k + "dp_c_reg"][ok]
+        # the NaN row makes the reference's reg gradient NaN for that row only
+        # reg gradient is proportional to W, which cancels to ~0 on some rows: absolute floor from the fixture scale
+        tol = 3e-5 * np.abs(ref).max(axis=1, keepdims=True) + 1e-5 * np.abs(ref[soft[ok]]).max()
+        assert np.all((np.abs(dpr - ref) <= tol)[soft[ok]]), (c, variant)
+
+
+def test_synth_dq_matches_reference_without_nan_row(golden):
+    """dq sums over rows, so the NaN row poisons the fixture's dq; recompute the reference value from
+    the fixture's own dW and the reference-produced W is impossible, so pin dq on the linear fixture
+    and on the whole-model fixture instead (no degenerate rows there)."""
+    g = golden("linear")
+    for c in _cases(g):
+        k = "c%02d_" % c
+        if g[k + "dq"].size == 0:
+            continue
+        dp, dq = O.synth_bwd(g[k + "p_c"], g[k + "q"], 3.0, g[k + "dW"], 0.0)
+        ref = g[k + "dq"]
+        assert np.abs(dq - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-7
+        ref = g[k + "dp_c"]
+        assert np.abs(dp - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_conv_matches_reference(golden):
+    g = golden("conv")
+    for c in _cases(g):
+        k = "c%02d_" % c
+        cin, cout, stride, H, N = [int(v) for v in g[k + "shape"]]
+        x, W, dy = g[k + "x"], g[k + "W"], g[k + "dy"]
+        y = O.conv_fwd(x, W, stride, 1)
+        assert y.shape == g[k + "y"].shape
+        assert np.abs(y - g[k + "y"]).max() <= 2e-5 * np.abs(g[k + "y"]).max()
+        dx = O.conv_dgrad(dy, W, x.shape, stride, 1)
+        assert np.abs(dx - g[k + "dx"]).max() <= 2e-5 * np.abs(g[k + "dx"]).max()
+        dW = O.conv_wgrad(x, dy, 3, stride, 1)
+        assert np.abs(dW - g[k + "dW"]).max() <= 2e-5 * np.abs(g[k + "dW"]).max()
+
+
+def test_linear_matches_reference(golden):
+    g = golden("linear")
+    for c in _cases(g):
+        k = "c%02d_" % c
+        W = O.synth_fwd(g[k + "p_c"], g[k + "q"], 3.0)["W"]
+        assert W.shape == (64, 10)  # (in, out) layout
+        assert np.abs(W - g[k + "W"]).max() <= 2e-6 * np.abs(g[k + "q"]).max()
+        y = O.linear_fwd(g[k + "x"], W, g[k + "bias"])
+        assert np.abs(y - g[k + "y"]).max() <= 1e-5 * np.abs(g[k + "y"]).max()
+        dx, dW, db = O.linear_bwd(g[k + "x"], W, g[k + "g"])
+        assert np.abs(dx - g[k + "dx"]).max() <= 1e-5 * np.abs(g[k + "dx"]).max()
+        assert np.abs(dW - g[k + "dW"]).max() <= 1e-5 * np.abs(g[k + "dW"]).max()
+        assert np.abs(db - g[k + "dbias"]).max() <= 1e-5 * np.abs(g[k + "dbias"]).max()
+
+
+def test_level_initialisers_match_reference(golden):
+    g = golden("levels")
+    for i in range(int(g["ncase"])):
+        s, L, liar = g["arg_%02d" % i]
+        L = int(L)
+        fx = O.levels_fix(float(s), L, bool(liar))
+        assert fx.shape == (L - 1,)
+        assert np.array_equal(fx, g["fix_%02d" % i]) and np.array_equal(fx, g["fixfc_%02d" % i])
+        if liar:  # hint has no liar switch; its fixtures were generated for both settings identically
+            hx = O.levels_hint(float(s), L)
+            assert hx.shape == (L,)
+            assert np.array_equal(hx, g["hint_%02d" % i]) and np.array_equal(hx, g["hintfc_%02d" % i])
+    # known answer quoted from the reference run for s = 0.3
+    fx = O.levels_fix(0.3, 32)
+    assert fx[0] == -0.25 and fx[15] == 0.0 and fx[-1] == 0.25 and fx[16] == 2.0 ** -16
+    hx = O.levels_hint(0.3, 32)
+    assert hx[0] == -0.25 and hx[16] == 2.0 ** -17 and hx[-1] == 0.25
+    for fan_in, obs in g["fan_bound_obs"]:
+        b = O.fan_bound(fan_in)
+        assert obs <= b and obs >= 0.99 * b
+
+
+def test_expf_accuracy():
+    x = np.linspace(-20, 20, 20001).astype(np.float32)
+    got = O.expf(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 1.3e-7
+    assert O.expf(np.float32(100.0)) == np.inf and O.expf(np.float32(-200.0)) == 0.0
+    assert np.isnan(O.expf(np.float32(np.nan)))
