@@ -1,0 +1,94 @@
+/*
+ * C ABI of libaq_hip.so: the MI355X (gfx950) kernels behind the reference's quantized
+ * layers.  The reference is pure Python on PyTorch and has no FFI of its own; each entry point
+ * below names the reference code whose arithmetic it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (unless typed otherwise) owned by the
+ *     caller; the library never allocates, frees or synchronises; scratch memory is the
+ *     caller-provided `workspace`;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value 0 on success, a negative errno-style code on failure, with a message available
+ *     from aq_last_error() (thread-local);
+ *   - calls on different streams may run concurrently as long as their buffers are distinct.
+ */
+#ifndef AQ_HIP_H
+#define AQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQ_ABI_VERSION 1
+#define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
+#define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
+
+/* One quantized layer ("segment") of a multi-layer launch.  rows = number of weights of the layer
+ * (Cout*Cin*k*k for MyConv2d.p_c, in*out for MyLinear.p_c), L = number of levels (innermost,
+ * contiguous axis of p_c).  Unused outputs may be NULL. */
+typedef struct aq_seg {
+    const float *p_c;   /* [rows, L] primary coefficients                                    */
+    const float *q;     /* [L]       quantisation levels                                     */
+    int64_t rows;
+    int32_t L;
+    int32_t reserved;
+    /* forward outputs */
+    float *W;           /* [rows] soft weight  sum_l s_c[l]*q[l]      (fan.py:563-568)       */
+    uint8_t *idx;       /* [rows] code = argmax_l s_c[l]              (fan_test.py:304)      */
+    float *W_hard;      /* [rows] q[idx]                              (fan_test.py:305)      */
+    float *sumsq;       /* [1]    sum_rows W^2, the layer's term of model_loss (fan.py:752)  */
+    /* backward inputs / outputs */
+    const float *dW;    /* [rows] d loss / d W (NULL = zero)                                 */
+    float *dp_c;        /* [rows, L] d loss / d p_c                                          */
+    float *dq;          /* [L]    d loss / d q_level (NULL for frozen levels, fix.py:652)    */
+} aq_seg;
+
+int aq_abi_version(void);
+const char *aq_last_error(void);
+
+/* Weight synthesis of nseg layers in one launch (+ one small reduction launch when any sumsq is
+ * requested).  Replaces MyConv2d.forward lines adp_qtz_fan.py:563-571 / MyLinear.forward
+ * :634-643 and the per-layer re-synthesis inside model_loss :747-752.
+ * workspace must hold aq_synth_workspace_bytes(segs, nseg, 0) bytes. */
+int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* Gradient of the synthesis: for every layer g = dW + wd*W (wd = 2*l2_reg*dLoss/dReg folds the
+ * regulariser of adp_qtz_fan.py:737-754 in), then dp_c and dq as autograd derives them from
+ * adp_qtz_fan.py:563-568.  workspace must hold aq_synth_workspace_bytes(segs, nseg, 1) bytes. */
+int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, void *workspace,
+                 size_t workspace_bytes, void *stream);
+
+size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward);
+
+/* 3x3 / pad 1 / stride 1|2 convolution, NCHW fp32, no bias: MyConv2d.forward lines
+ * adp_qtz_fan.py:574-601 (== cross-correlation).  W is [Cout, Cin, 3, 3]. */
+int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H, int Wd, int Cout,
+                int ksize, int stride, int pad, void *stream);
+/* same, weights given as codes + levels (hard mode, adp_qtz_fan_test.py:304-331): W = q[idx] is
+ * decoded while the weight tile is staged into LDS. */
+int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L, float *y, int N,
+                      int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream);
+/* dx = d loss / d x  (autograd of adp_qtz_fan.py:574-601 w.r.t. the input) */
+int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd,
+                  int Cout, int ksize, int stride, int pad, void *stream);
+/* dW = d loss / d W  (autograd of adp_qtz_fan.py:574-601 w.r.t. conv_w); deterministic two-stage
+ * reduction through `workspace` (aq_conv_wgrad_workspace_bytes). */
+int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd,
+                  int Cout, int ksize, int stride, int pad, void *workspace, size_t workspace_bytes,
+                  void *stream);
+size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
+                                     int pad);
+
+/* MyLinear (adp_qtz_fan.py:646-647): y[N,Out] = x[N,In] @ W[In,Out] + bias[Out]; and its gradients
+ * dx[N,In], dW[In,Out], dbias[Out] (any of the three may be NULL). */
+int aq_linear_fwd(const float *x, const float *W, const float *bias, float *y, int N, int In, int Out,
+                  void *stream);
+int aq_linear_bwd(const float *x, const float *W, const float *dy, float *dx, float *dW, float *dbias,
+                  int N, int In, int Out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQ_HIP_H */

@@ -26,7 +26,8 @@
  *   - a per-lane partial is a left-to-right chain over the lane's 4 elements;
  *   - lane partials are combined by an xor butterfly (masks 1,2,4,..,G/2),
  *     i.e. a balanced binary tree in natural lane order;
- *   - exp() is aqo_expf below (Cody-Waite reduction + degree-5 polynomial).
+ *   - exp() is aqo_expf below (Cody-Waite reduction + degree-5 polynomial);
+ *   - W = (sum_l e_l*q_l) * (1/sum_l e_l), s_l = e_l * (1/sum_l e_l), 1/||p|| = 1/sqrtf(sum p^2).
  * Sums that run ACROSS rows (sum W^2, dq_level, conv accumulations) are kept
  * in double here; the kernels reduce them in fp32 in a fixed, documented order
  * and are compared within a tolerance.
@@ -55,7 +56,7 @@
 /* ------------------------------------------------------------------ exp --- */
 /* exp(x) for binary32, ~1 ulp: x = q*ln2 + s, |s| <= ln2/2, two-constant
  * reduction, polynomial in s, scale by 2^q.  Same operation sequence as the
- * device function aq_expf in quantized-cnn_amd/csrc/aq_arith.h. */
+ * device function aq::expf_spec in quantized-cnn_amd/csrc/aq_arith.h. */
 AQO_INLINE float expf_spec(float x)
 {
     const float R_LN2 = 1.442695040888963407359924681001892137426645954152985934135449406931f;
@@ -71,12 +72,10 @@ AQO_INLINE float expf_spec(float x)
     u = fmaf(u, s, 0.166666671633720397949219f);
     u = fmaf(u, s, 0.5f);
     u = 1.0f + fmaf(s * s, u, s);
-    float r;
-    if (x > 88.72283905206835f) r = INFINITY;
-    else if (x < -104.0f) r = 0.0f;
-    else if (x != x) r = x + x;
-    else r = ldexpf(u, (int)qf);
-    return r;
+    /* Domain |x| <= 64 (callers bound |beta|; |p/||p||| <= 1): 2^q*u neither overflows nor
+     * underflows there, so no range checks are part of the sequence.  NaN in -> NaN out. */
+    const int qi = (qf == qf) ? (int)qf : 0;
+    return ldexpf(u, qi);
 }
 
 float aqo_expf(float x) { return expf_spec(x); }
@@ -91,15 +90,6 @@ AQO_INLINE float tree(float *v, int G)
         memcpy(v, t, sizeof(float) * G);
     }
     return v[0];
-}
-
-/* key used for the arg-max over s_c: NaN is maximal (torch.max semantics,
- * adp_qtz_fan_test.py:304), every NaN compares equal, ties -> lowest index. */
-AQO_INLINE uint32_t amax_key(float s)
-{
-    uint32_t b;
-    memcpy(&b, &s, 4);
-    return (s != s) ? 0x7fc00000u : (b & 0x7fffffffu);
 }
 
 typedef struct {
@@ -131,18 +121,21 @@ AQO_INLINE void row_forward(const float *p, const float *q, int L, float beta, r
     const float rden = 1.0f / den;
     for (int i = 0; i < LP; ++i) st->s[i] = e[i] * rden;
     for (int j = 0; j < G; ++j) {
-        const float *s = st->s + 4 * j, *b = qq + 4 * j;
-        float t = s[0] * b[0];
-        t = fmaf(s[1], b[1], t); t = fmaf(s[2], b[2], t); t = fmaf(s[3], b[3], t);
+        const float *a = e + 4 * j, *b = qq + 4 * j;
+        float t = a[0] * b[0];
+        t = fmaf(a[1], b[1], t); t = fmaf(a[2], b[2], t); t = fmaf(a[3], b[3], t);
         v[j] = t;
     }
-    st->W = tree(v, G);
+    st->W = tree(v, G) * rden;
     st->rn = rn;
-    uint32_t best = amax_key(st->s[0]);
+    /* code = arg-max over the softmax coefficients (adp_qtz_fan_test.py:304).  e -> e/den is
+     * monotone, so the arg-max is taken over e (ties -> lowest index, as torch.max); when the
+     * denominator is NaN every coefficient is NaN and torch.max returns index 0. */
     int bi = 0;
-    for (int i = 1; i < L; ++i) {
-        uint32_t k = amax_key(st->s[i]);
-        if (k > best) { best = k; bi = i; }
+    if (den == den) {
+        float best = e[0];
+        for (int i = 1; i < L; ++i)
+            if (e[i] > best) { best = e[i]; bi = i; }
     }
     st->idx = bi;
 }

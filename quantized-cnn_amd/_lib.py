@@ -1,0 +1,90 @@
+"""ctypes binding of libaq_hip.so (C ABI: include/aq_hip.h).
+
+There is no fallback: if the library is missing, loading raises; if a call fails, the message of
+aq_last_error() is raised as RuntimeError.  Tensors handed to the kernels must be CUDA(HIP), fp32
+(uint8 for codes) and contiguous; anything else raises ValueError before the call.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaq_hip.so")
+ABI_VERSION = 1
+MAX_LEVELS = 128
+
+EXPORTS = (
+    "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
+    "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
+    "aq_linear_fwd", "aq_linear_bwd",
+)
+
+
+class AqSeg(C.Structure):
+    _fields_ = [
+        ("p_c", C.c_void_p), ("q", C.c_void_p), ("rows", C.c_int64), ("L", C.c_int32), ("reserved", C.c_int32),
+        ("W", C.c_void_p), ("idx", C.c_void_p), ("W_hard", C.c_void_p), ("sumsq", C.c_void_p),
+        ("dW", C.c_void_p), ("dp_c", C.c_void_p), ("dq", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C quantized-cnn_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        L.aq_abi_version.restype = i
+        L.aq_last_error.restype = C.c_char_p
+        L.aq_synth_fwd.argtypes = [C.POINTER(AqSeg), i, f, vp, sz, vp]
+        L.aq_synth_bwd.argtypes = [C.POINTER(AqSeg), i, f, f, vp, sz, vp]
+        L.aq_synth_workspace_bytes.argtypes = [C.POINTER(AqSeg), i, i]
+        L.aq_synth_workspace_bytes.restype = sz
+        conv_dims = [i] * 8
+        L.aq_conv_fwd.argtypes = [vp, vp, vp] + conv_dims + [vp]
+        L.aq_conv_fwd_codes.argtypes = [vp, vp, vp, i, vp] + conv_dims + [vp]
+        L.aq_conv_dgrad.argtypes = [vp, vp, vp] + conv_dims + [vp]
+        L.aq_conv_wgrad.argtypes = [vp, vp, vp] + conv_dims + [vp, sz, vp]
+        L.aq_conv_wgrad_workspace_bytes.argtypes = conv_dims
+        L.aq_conv_wgrad_workspace_bytes.restype = sz
+        L.aq_linear_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+        L.aq_linear_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
+        for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad",
+                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd"):
+            getattr(L, name).restype = i
+        if L.aq_abi_version() != ABI_VERSION:
+            raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libaq_hip: %s (code %d)" % (lib().aq_last_error().decode(), rc))
+
+
+def ptr(t, dtype=torch.float32, name="tensor"):
+    """Device pointer of a tensor after checking it is what the kernels assume."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s: expected a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s lives on %s: the quantized layers run on the HIP device only "
+                           "(no CPU path); move the model and its inputs to cuda" % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError("%s: dtype %s, expected %s" % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

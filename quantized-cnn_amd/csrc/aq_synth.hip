@@ -1,0 +1,483 @@
+// Weight synthesis ("adaptive quantisation") kernels for gfx950 and their C-ABI entry points.
+//
+//   forward  : W = sum_l softmax(beta * p_c/||p_c||)_l * q_l   (adp_qtz_fan.py:563-568)
+//              idx = argmax_l s_c, W_hard = q[idx]             (adp_qtz_fan_test.py:304-305)
+//              sumsq = sum_rows W^2                            (adp_qtz_fan.py:752)
+//   backward : dp_c, dq for g = dW + wd*W                      (autograd of the above)
+//
+// Both are HBM-bound streaming kernels over p_c (L floats per weight):
+//   - a wavefront reads 64 consecutive rows per iteration as G-lane groups of 16-byte loads, so
+//     every load instruction covers 1 KiB of contiguous memory; 8 loads per lane are issued
+//     before the first is consumed;
+//   - all per-row reductions stay inside the G lanes of a row (DPP, no LDS, no barrier);
+//   - after the 64 rows are done, lane (g, j) keeps the result of row j*(64/G)+g, so W / idx are
+//     written with one fully coalesced store per iteration;
+//   - sums over rows (sum W^2, dq) are accumulated per lane over K iterations, reduced inside the
+//     wavefront and written as one partial per wavefront; a second tiny kernel adds the partials
+//     of each layer in a fixed order.  No atomics: results are run-to-run deterministic.
+//   - several layers ("segments") share one launch through a table passed by value in kernarg.
+#include "aq_arith.h"
+#include "aq_common.h"
+#include "../../include/aq_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace aq {
+
+constexpr int MAX_SEGS = 24;  // segments per launch (kernarg budget)
+constexpr int WAVES = 4;      // wavefronts per workgroup
+constexpr int ROWS_IT = 64;   // rows per wavefront iteration
+
+struct SegDev {
+    const float *p, *q, *dW;
+    float *W, *Wh, *dp, *part;
+    uint8_t *idx;
+    long long rows;
+    int L, blk0;
+};
+struct SegTab {
+    int nseg, K;
+    SegDev s[MAX_SEGS];
+};
+
+template <int G, bool VEC>
+__device__ __forceinline__ void load_elems(const float *__restrict__ p, long long r, int L, int j, float (&v)[4])
+{
+    if constexpr (VEC) {
+        const float4 t = reinterpret_cast<const float4 *>(p)[r * G + j];
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        const float *a = p + r * (long long)L + 4 * j;
+        if (4 * j + 3 < L) {
+            float4 t;
+            __builtin_memcpy(&t, a, 16);  // rows are only 4-byte aligned here
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (4 * j + k < L) ? a[k] : 0.0f;
+        }
+    }
+}
+
+template <int G, bool VEC>
+__device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, int L, int j, const float (&v)[4])
+{
+    if constexpr (VEC) {
+        reinterpret_cast<float4 *>(p)[r * G + j] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        float *a = p + r * (long long)L + 4 * j;
+        if (4 * j + 3 < L) {
+            const float4 t = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_memcpy(a, &t, 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * j + k < L) a[k] = v[k];
+        }
+    }
+}
+
+__device__ __forceinline__ int find_segment(const SegTab &tab)
+{
+    int si = 0;
+    for (int i = 1; i < tab.nseg; ++i)
+        if ((int)blockIdx.x >= tab.s[i].blk0) si = i;
+    return si;
+}
+
+template <int G, bool VEC, bool HARD>
+__global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
+{
+    constexpr int RPP = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane % G, gq = lane / G;
+    const int si = find_segment(tab);
+    const float *__restrict__ p = tab.s[si].p;
+    const float *__restrict__ q = tab.s[si].q;
+    float *__restrict__ W = tab.s[si].W;
+    float *__restrict__ Wh = tab.s[si].Wh;
+    uint8_t *__restrict__ idx = tab.s[si].idx;
+    float *__restrict__ part = tab.s[si].part;
+    const long long rows = tab.s[si].rows;
+    const int L = tab.s[si].L;
+
+    const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
+    const long long row_begin = wt * tab.K * ROWS_IT;
+    if (row_begin >= rows) return;
+
+    float q4[4];
+    bool valid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        valid[k] = 4 * j + k < L;
+        q4[k] = valid[k] ? q[4 * j + k] : 0.0f;
+    }
+
+    float acc = 0.0f;
+    for (int it = 0; it < tab.K; ++it) {
+        const long long row0 = row_begin + (long long)it * ROWS_IT;
+        if (row0 >= rows) break;
+        float myW = 0.0f;
+        uint32_t myIdx = 0;
+        static_for<G / 8>([&](auto UB) {
+            constexpr int ub = 8 * decltype(UB)::value;
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = row0 + (ub + u) * RPP + gq;
+                load_elems<G, VEC>(p, r < rows ? r : rows - 1, L, j, v[u]);
+            }
+            // squared norms of the 8 rows; lane j == ub+u keeps row u's and inverts it once
+            float my_ss = 1.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float ss = group_sum<G>(chain_sq(v[u]));
+                my_ss = (j == ub + u) ? ss : my_ss;
+            }
+            const float my_rn = inv_norm(my_ss);
+            float my_den = 1.0f, my_num = 0.0f;
+            uint32_t my_bi = 0;
+            static_for<8>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const float rn = group_bcast<G, ub + u>(my_rn);
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ex = expf_spec(beta * (v[u][k] * rn));
+                    e[k] = (VEC || valid[k]) ? ex : 0.0f;
+                }
+                const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
+                const float num = group_sum<G>(chain_dot(e, q4));
+                uint32_t bi = 0;
+                if constexpr (HARD) {
+                    uint32_t bk = __builtin_bit_cast(uint32_t, e[0]);
+                    bi = 4 * j;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const uint32_t kk = __builtin_bit_cast(uint32_t, e[k]);
+                        const bool take = kk > bk;  // padding is 0 with a larger index: never wins
+                        bk = take ? kk : bk;
+                        bi = take ? 4 * j + k : bi;
+                    }
+                    group_argmax<G>(bk, bi);
+                }
+                const bool mine = (j == ub + u);
+                my_den = mine ? den : my_den;
+                my_num = mine ? num : my_num;
+                my_bi = mine ? bi : my_bi;
+            });
+            const float w = my_num * (1.0f / my_den);
+            const bool owner = (j >= ub) && (j < ub + 8);
+            myW = owner ? w : myW;
+            if constexpr (HARD) myIdx = owner ? ((my_den == my_den) ? my_bi : 0u) : myIdx;
+        });
+        // lane (gq, j) now holds row j*RPP + gq of this iteration: one coalesced store each
+        const long long rr = row0 + (long long)j * RPP + gq;
+        if (rr < rows) {
+            if (W) W[rr] = myW;
+            if constexpr (HARD) {
+                if (idx) idx[rr] = (uint8_t)myIdx;
+                if (Wh) Wh[rr] = q[myIdx];
+            }
+            acc = __builtin_fmaf(myW, myW, acc);
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) part[wt] = acc;
+    }
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd)
+{
+    constexpr int RPP = 64 / G;
+    constexpr int LP = 4 * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane % G, gq = lane / G;
+    const int si = find_segment(tab);
+    const float *__restrict__ p = tab.s[si].p;
+    const float *__restrict__ q = tab.s[si].q;
+    const float *__restrict__ dW = tab.s[si].dW;
+    float *__restrict__ dp = tab.s[si].dp;
+    float *__restrict__ part = tab.s[si].part;
+    const long long rows = tab.s[si].rows;
+    const int L = tab.s[si].L;
+
+    const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
+    const long long row_begin = wt * tab.K * ROWS_IT;
+    if (row_begin >= rows) return;
+
+    float q4[4];
+    bool valid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        valid[k] = 4 * j + k < L;
+        q4[k] = valid[k] ? q[4 * j + k] : 0.0f;
+    }
+
+    float accq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < tab.K; ++it) {
+        const long long row0 = row_begin + (long long)it * ROWS_IT;
+        if (row0 >= rows) break;
+        static_for<G / 8>([&](auto UB) {
+            constexpr int ub = 8 * decltype(UB)::value;
+            float v[8][4];
+            float gw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = row0 + (ub + u) * RPP + gq;
+                const long long rc = r < rows ? r : rows - 1;
+                load_elems<G, VEC>(p, rc, L, j, v[u]);
+                gw[u] = dW ? dW[rc] : 0.0f;
+            }
+            float my_ss = 1.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float ss = group_sum<G>(chain_sq(v[u]));
+                my_ss = (j == ub + u) ? ss : my_ss;
+            }
+            const float my_rn = inv_norm(my_ss);
+            static_for<8>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const long long r = row0 + (ub + u) * RPP + gq;
+                const float rn = group_bcast<G, ub + u>(my_rn);
+                float pn[4], e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pn[k] = v[u][k] * rn;
+                    const float ex = expf_spec(beta * pn[k]);
+                    e[k] = (VEC || valid[k]) ? ex : 0.0f;
+                }
+                const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
+                const float num = group_sum<G>(chain_dot(e, q4));
+                const float rden = 1.0f / den;
+                const float w = num * rden;
+                const float g = __builtin_fmaf(wd, w, gw[u]);
+                const float dot = g * w;
+                float s[4], gpn[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s[k] = e[k] * rden;
+                    const float gs = g * q4[k];
+                    gpn[k] = beta * (s[k] * (gs - dot));
+                }
+                const float dpn = group_sum<G>(chain_dot(pn, gpn));
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
+                if (r < rows) {
+                    store_elems<G, VEC>(dp, r, L, j, o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                }
+            });
+        });
+    }
+    if (part) {
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) accq[k] += __shfl_xor(accq[k], m);
+        }
+        if (gq == 0) {
+            float *o = part + wt * LP + 4 * j;
+            reinterpret_cast<float4 *>(o)[0] = make_float4(accq[0], accq[1], accq[2], accq[3]);
+        }
+    }
+}
+
+// Second stage of the cross-row sums: one workgroup per layer adds the layer's per-wavefront
+// partials.  Thread (ln, lvl) adds partials ln, ln+NL, ln+2NL, .. of column lvl in that order,
+// then the NL running sums of a column are combined by a halving tree in LDS.
+struct RedSeg {
+    const float *part;
+    float *out;
+    long long n;
+    int width, outw;
+};
+struct RedTab {
+    int nseg;
+    RedSeg s[MAX_SEGS];
+};
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const RedTab tab)
+{
+    __shared__ float sh[1024];
+    const RedSeg sg = tab.s[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int width = sg.width, nl = 1024 / width;
+    const int lvl = tid % width, ln = tid / width;
+    float a = 0.0f;
+    for (long long i = ln; i < sg.n; i += nl) a += sg.part[i * width + lvl];
+    sh[tid] = a;
+    __syncthreads();
+    for (int s = nl >> 1; s >= 1; s >>= 1) {
+        if (ln < s) sh[tid] += sh[tid + s * width];
+        __syncthreads();
+    }
+    if (ln == 0 && lvl < sg.outw) sg.out[lvl] = sh[lvl];
+}
+
+// ------------------------------------------------------------------------------------ host side
+
+static inline int lanes_for(int L) { return L <= 32 ? 8 : (L <= 64 ? 16 : 32); }
+
+static inline int choose_K(long long total_rows)
+{
+    long long k = total_rows / (256LL * 4096LL);
+    return (int)std::min<long long>(16, std::max<long long>(1, k));
+}
+
+static inline long long wave_tiles(long long rows, int K) { return (rows + (long long)K * ROWS_IT - 1) / ((long long)K * ROWS_IT); }
+
+struct Plan {
+    int K;
+    size_t bytes;
+    size_t off[1 << 12];
+};
+
+static int validate(const aq_seg *segs, int nseg, float beta, bool bwd)
+{
+    AQ_REQUIRE(segs != nullptr && nseg >= 1 && nseg <= (1 << 12), -EINVAL, "segs must hold 1..4096 segments (got %d)", nseg);
+    AQ_REQUIRE(beta == beta && std::abs(beta) <= AQ_MAX_ABS_BETA, -EDOM, "beta=%g outside [-%g, %g]", (double)beta,
+               (double)AQ_MAX_ABS_BETA, (double)AQ_MAX_ABS_BETA);
+    for (int i = 0; i < nseg; ++i) {
+        const aq_seg &s = segs[i];
+        AQ_REQUIRE(s.L >= 1 && s.L <= AQ_MAX_LEVELS, -EINVAL, "segment %d: L=%d outside 1..%d", i, s.L, AQ_MAX_LEVELS);
+        AQ_REQUIRE(s.rows >= 0, -EINVAL, "segment %d: negative row count", i);
+        AQ_REQUIRE(s.rows == 0 || (s.p_c && s.q), -EFAULT, "segment %d: p_c / q is NULL", i);
+        AQ_REQUIRE(((uintptr_t)s.p_c & 3) == 0 && ((uintptr_t)s.q & 3) == 0, -EINVAL, "segment %d: misaligned pointer", i);
+        if (bwd) AQ_REQUIRE(s.rows == 0 || s.dp_c, -EFAULT, "segment %d: dp_c is NULL", i);
+    }
+    return 0;
+}
+
+static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
+{
+    long long total = 0;
+    for (int i = 0; i < nseg; ++i) total += segs[i].rows;
+    pl.K = choose_K(total);
+    size_t off = 0;
+    for (int i = 0; i < nseg; ++i) {
+        pl.off[i] = off;
+        const bool need = bwd ? segs[i].dq != nullptr : segs[i].sumsq != nullptr;
+        if (need && segs[i].rows > 0) {
+            const size_t width = bwd ? 4 * lanes_for(segs[i].L) : 1;
+            size_t n = (size_t)wave_tiles(segs[i].rows, pl.K) * width * sizeof(float);
+            off += (n + 255) & ~(size_t)255;
+        }
+    }
+    pl.bytes = off;
+}
+
+template <bool BWD>
+static void launch_class(int G, bool vec, bool hard, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
+{
+#define AQ_LAUNCH(GG, VV)                                                                                           \
+    if (BWD)                                                                                                        \
+        hipLaunchKernelGGL((synth_bwd_kernel<GG, VV>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);             \
+    else if (hard)                                                                                                  \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);           \
+    else                                                                                                            \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
+    if (G == 8) { if (vec) { AQ_LAUNCH(8, true) } else { AQ_LAUNCH(8, false) } }
+    else if (G == 16) { if (vec) { AQ_LAUNCH(16, true) } else { AQ_LAUNCH(16, false) } }
+    else { if (vec) { AQ_LAUNCH(32, true) } else { AQ_LAUNCH(32, false) } }
+#undef AQ_LAUNCH
+}
+
+template <bool BWD>
+static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspace, size_t workspace_bytes, hipStream_t st)
+{
+    if (int rc = validate(segs, nseg, beta, BWD)) return rc;
+    static thread_local Plan pl;
+    make_plan(segs, nseg, BWD, pl);
+    AQ_REQUIRE(pl.bytes == 0 || (workspace && workspace_bytes >= pl.bytes), -ENOSPC, "workspace too small: need %zu bytes, got %zu",
+               pl.bytes, workspace_bytes);
+    AQ_REQUIRE(((uintptr_t)workspace & 15) == 0, -EINVAL, "workspace must be 16-byte aligned");
+
+    // main launches: one per (lanes-per-row, vector-aligned) class, at most MAX_SEGS segments each
+    for (int G = 8; G <= 32; G <<= 1)
+        for (int vec = 0; vec < 2; ++vec) {
+            SegTab tab;
+            tab.nseg = 0;
+            tab.K = pl.K;
+            int nblocks = 0;
+            bool hard = false;
+            auto flush = [&]() {
+                if (tab.nseg) launch_class<BWD>(G, vec != 0, hard, tab, nblocks, beta, wd, st);
+                tab.nseg = 0;
+                nblocks = 0;
+                hard = false;
+            };
+            for (int i = 0; i < nseg; ++i) {
+                const aq_seg &s = segs[i];
+                if (s.rows == 0 || lanes_for(s.L) != G) continue;
+                bool v = (s.L == 4 * G) && (((uintptr_t)s.p_c & 15) == 0);
+                if (BWD) v = v && (((uintptr_t)s.dp_c & 15) == 0);
+                if ((int)v != vec) continue;
+                SegDev &d = tab.s[tab.nseg];
+                d.p = s.p_c; d.q = s.q; d.dW = s.dW; d.W = s.W; d.Wh = s.W_hard; d.dp = s.dp_c; d.idx = s.idx;
+                const bool need = BWD ? s.dq != nullptr : s.sumsq != nullptr;
+                d.part = need ? reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.off[i]) : nullptr;
+                d.rows = s.rows; d.L = s.L; d.blk0 = nblocks;
+                hard = hard || s.idx != nullptr || s.W_hard != nullptr;
+                const long long nb = (wave_tiles(s.rows, pl.K) + WAVES - 1) / WAVES;
+                AQ_REQUIRE(nb + nblocks < (1LL << 31), -E2BIG, "segment %d: too many rows for one launch", i);
+                nblocks += (int)nb;
+                if (++tab.nseg == MAX_SEGS) flush();
+            }
+            flush();
+        }
+    if (int rc = check_launch(BWD ? "aq_synth_bwd" : "aq_synth_fwd")) return rc;
+
+    // second stage: fixed-order sum of the per-wavefront partials of each layer
+    RedTab red;
+    red.nseg = 0;
+    auto flush_red = [&]() {
+        if (red.nseg) hipLaunchKernelGGL(reduce_partials_kernel, dim3(red.nseg), dim3(1024), 0, st, red);
+        red.nseg = 0;
+    };
+    for (int i = 0; i < nseg; ++i) {
+        const aq_seg &s = segs[i];
+        float *out = BWD ? s.dq : s.sumsq;
+        if (!out) continue;
+        RedSeg &r = red.s[red.nseg];
+        r.part = reinterpret_cast<const float *>(static_cast<const char *>(workspace) + pl.off[i]);
+        r.out = out;
+        r.n = s.rows ? wave_tiles(s.rows, pl.K) : 0;
+        r.width = BWD ? 4 * lanes_for(s.L) : 1;
+        r.outw = BWD ? s.L : 1;
+        if (++red.nseg == MAX_SEGS) flush_red();
+    }
+    flush_red();
+    return check_launch(BWD ? "aq_synth_bwd(reduce)" : "aq_synth_fwd(reduce)");
+}
+
+} // namespace aq
+
+extern "C" {
+
+int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return aq::run<false>(segs, nseg, beta, 0.0f, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return aq::run<true>(segs, nseg, beta, wd, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward)
+{
+    if (!segs || nseg < 1 || nseg > (1 << 12)) return 0;
+    static thread_local aq::Plan pl;
+    aq::make_plan(segs, nseg, backward != 0, pl);
+    return pl.bytes;
+}
+
+} // extern "C"

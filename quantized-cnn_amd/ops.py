@@ -1,0 +1,171 @@
+"""Tensor-level wrappers over the HIP kernels (no autograd here; see `layers` for the Functions).
+
+Every function launches on torch's current HIP stream, allocates its outputs and workspace through
+torch's caching allocator (so calls are capturable in a HIP graph), and never synchronises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _rows_L(p):
+    L = p.shape[-1]
+    return p.numel() // max(L, 1), L
+
+
+def _seg_array(p_list, q_list):
+    n = len(p_list)
+    if n == 0 or n != len(q_list):
+        raise ValueError("need one q_level per p_c (got %d / %d)" % (n, len(q_list)))
+    segs = (_lib.AqSeg * n)()
+    for i, (p, q) in enumerate(zip(p_list, q_list)):
+        rows, L = _rows_L(p)
+        if q.numel() != L:
+            raise ValueError("segment %d: p_c has %d levels but q_level has %d" % (i, L, q.numel()))
+        segs[i].p_c = _lib.ptr(p, name="p_c[%d]" % i)
+        segs[i].q = _lib.ptr(q, name="q_level[%d]" % i)
+        segs[i].rows, segs[i].L = rows, L
+    return segs
+
+
+def _workspace(segs, n, backward, device):
+    nbytes = _lib.lib().aq_synth_workspace_bytes(segs, n, int(backward))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    return ws, nbytes
+
+
+def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out_W=None):
+    """Weight synthesis of several layers in one launch.
+
+    p_list[i]: (..., L_i) fp32, q_list[i]: (L_i,).  Returns a dict with (as requested)
+      "W"      list of soft weights, shape p.shape[:-1]          (adp_qtz_fan.py:563-568)
+      "idx"    list of uint8 codes, "W_hard" list of q[idx]      (adp_qtz_fan_test.py:304-305)
+      "sumsq"  fp32 tensor [n]: sum of W^2 per layer             (adp_qtz_fan.py:752)
+    out_W: optional list of preallocated fp32 tensors to receive W.
+    """
+    n = len(p_list)
+    segs = _seg_array(p_list, q_list)
+    dev = p_list[0].device
+    out = {}
+    if soft:
+        out["W"] = out_W if out_W is not None else [torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) for p in p_list]
+        for i, w in enumerate(out["W"]):
+            if w.numel() != segs[i].rows:
+                raise ValueError("out_W[%d] has %d elements, expected %d" % (i, w.numel(), segs[i].rows))
+            segs[i].W = _lib.ptr(w, name="W[%d]" % i)
+    if codes:
+        out["idx"] = [torch.empty(p.shape[:-1], dtype=torch.uint8, device=dev) for p in p_list]
+        out["W_hard"] = [torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) for p in p_list]
+        for i in range(n):
+            segs[i].idx = _lib.ptr(out["idx"][i], torch.uint8, "idx")
+            segs[i].W_hard = _lib.ptr(out["W_hard"][i], name="W_hard")
+    if sumsq:
+        out["sumsq"] = torch.empty(n, dtype=torch.float32, device=dev)
+        base = out["sumsq"].data_ptr()
+        for i in range(n):
+            segs[i].sumsq = base + 4 * i
+    ws, nbytes = _workspace(segs, n, False, dev)
+    _lib.check(_lib.lib().aq_synth_fwd(segs, n, float(beta), ws.data_ptr(), nbytes, _lib.stream()))
+    return out
+
+
+def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None):
+    """Gradient of the synthesis for several layers in one launch.
+
+    dW_list[i]: upstream d loss/d W (shape p.shape[:-1]) or None; wd = 2*l2_reg*(d loss/d reg).
+    need_dq[i] False skips dq (frozen levels).  Returns (dp_list, dq_list) with None where skipped.
+    """
+    n = len(p_list)
+    segs = _seg_array(p_list, q_list)
+    dev = p_list[0].device
+    need_dq = [True] * n if need_dq is None else list(need_dq)
+    dp = out_dp if out_dp is not None else [torch.empty_like(p) for p in p_list]
+    dq = [torch.empty_like(q) if need else None for q, need in zip(q_list, need_dq)]
+    for i in range(n):
+        if dW_list[i] is not None:
+            if dW_list[i].numel() != segs[i].rows:
+                raise ValueError("dW[%d] has %d elements, expected %d" % (i, dW_list[i].numel(), segs[i].rows))
+            segs[i].dW = _lib.ptr(dW_list[i], name="dW[%d]" % i)
+        segs[i].dp_c = _lib.ptr(dp[i], name="dp_c[%d]" % i)
+        if dq[i] is not None:
+            segs[i].dq = _lib.ptr(dq[i], name="dq[%d]" % i)
+    ws, nbytes = _workspace(segs, n, True, dev)
+    _lib.check(_lib.lib().aq_synth_bwd(segs, n, float(beta), float(wd), ws.data_ptr(), nbytes, _lib.stream()))
+    return dp, dq
+
+
+# ------------------------------------------------------------------------------------ convolution
+
+def _conv_dims(x_shape, Cout, stride):
+    N, Cin, H, Wd = x_shape
+    return [int(N), int(Cin), int(H), int(Wd), int(Cout), 3, int(stride), 1]
+
+
+def conv_out_shape(x_shape, Cout, stride):
+    N, _, H, Wd = x_shape
+    return (N, Cout, (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1)
+
+
+def conv_forward(x, W, stride=1):
+    """y = conv2d(x, W, stride, padding=1), W (Cout, Cin, 3, 3)  (adp_qtz_fan.py:574-601)."""
+    if W.dim() != 4 or W.shape[2] != 3 or W.shape[3] != 3 or x.dim() != 4 or W.shape[1] != x.shape[1]:
+        raise ValueError("conv_forward: x %s / W %s: need NCHW input and (Cout, Cin, 3, 3) weights" % (tuple(x.shape), tuple(W.shape)))
+    y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aq_conv_fwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(y), *_conv_dims(x.shape, W.shape[0], stride), _lib.stream()))
+    return y
+
+
+def conv_forward_codes(x, idx, q, stride=1):
+    """Hard-mode conv: weights given as uint8 codes (Cout, Cin, 3, 3) + levels q (L,)."""
+    if idx.dim() != 4 or idx.shape[1] != x.shape[1]:
+        raise ValueError("conv_forward_codes: idx %s does not match x %s" % (tuple(idx.shape), tuple(x.shape)))
+    y = torch.empty(conv_out_shape(x.shape, idx.shape[0], stride), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aq_conv_fwd_codes(_lib.ptr(x, name="x"), _lib.ptr(idx, torch.uint8, "idx"), _lib.ptr(q, name="q"), int(q.numel()),
+                                            _lib.ptr(y), *_conv_dims(x.shape, idx.shape[0], stride), _lib.stream()))
+    return y
+
+
+def conv_dgrad(dy, W, x_shape, stride=1):
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if tuple(dy.shape) != conv_out_shape(x_shape, W.shape[0], stride):
+        raise ValueError("conv_dgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x_shape)))
+    _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *_conv_dims(x_shape, W.shape[0], stride), _lib.stream()))
+    return dx
+
+
+def conv_wgrad(x, dy, stride=1, out=None):
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):
+        raise ValueError("conv_wgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    dW = out if out is not None else torch.empty((Cout, x.shape[1], 3, 3), dtype=torch.float32, device=x.device)
+    dims = _conv_dims(x.shape, Cout, stride)
+    nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_conv_wgrad(_lib.ptr(x, name="x"), _lib.ptr(dy, name="dy"), _lib.ptr(dW, name="dW"), *dims, ws.data_ptr(), nbytes, _lib.stream()))
+    return dW
+
+
+# ----------------------------------------------------------------------------------------- linear
+
+def linear_forward(x, W, bias):
+    """y = x @ W + bias with W (in, out)  (adp_qtz_fan.py:646-647)."""
+    N, In = x.shape
+    if W.shape[0] != In:
+        raise ValueError("linear_forward: x %s / W %s" % (tuple(x.shape), tuple(W.shape)))
+    Out = W.shape[1]
+    y = torch.empty((N, Out), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aq_linear_fwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(bias, name="bias"), _lib.ptr(y), N, In, Out, _lib.stream()))
+    return y
+
+
+def linear_backward(x, W, dy, need_dx=True):
+    N, In = x.shape
+    Out = W.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    dW = torch.empty_like(W)
+    db = torch.empty(Out, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aq_linear_bwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(dy, name="dy"), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db),
+                                        N, In, Out, _lib.stream()))
+    return dx, dW, db

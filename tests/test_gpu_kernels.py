@@ -1,0 +1,250 @@
+"""HIP kernels, called through the C ABI, against the CPU oracle and the reference fixtures.
+
+Bars: W, codes and dp_c are BIT-EXACT against the oracle (same IEEE-754 operation sequence);
+sums across rows (sum W^2, dq) and the convolutions are fp32 reductions in a different (fixed)
+order than the oracle's double accumulation: rel 2e-5 of the result's scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import quantized_cnn_amd.ops as ops
+DEV = "cuda"
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bits_equal(got, want, what):
+    g, w = bits(got), bits(want)
+    nan = np.isnan(got) & np.isnan(want)
+    bad = (g != w) & ~nan
+    assert not bad.any(), "%s: %d of %d values differ, first at %s: %r vs %r" % (
+        what, bad.sum(), bad.size, np.argwhere(bad)[0], got[tuple(np.argwhere(bad)[0])], want[tuple(np.argwhere(bad)[0])])
+
+
+def hint_levels(L, s=0.3):
+    return O.levels_hint(s, L) if L % 2 == 0 else O.levels_fix(s, L + 1)
+
+
+def rand_levels(rs, L):
+    return (rs.uniform(-1, 1, L) * 0.25).astype(np.float32)
+
+
+@pytest.mark.parametrize("L", [1, 3, 4, 8, 31, 32, 33, 48, 64, 65, 100, 128])
+@pytest.mark.parametrize("rows", [1, 7, 64, 65, 255, 1000, 4099])
+def test_synth_forward_bit_exact(L, rows):
+    rs = np.random.RandomState(L * 10007 + rows)
+    p = rs.standard_normal((rows, L)).astype(np.float32)
+    q = rand_levels(rs, L)
+    beta = float(rs.choice([1, 2, 3, 4, 0.5, -1.5]))
+    ref = O.synth_fwd(p, q, beta)
+    out = ops.synth_forward([cu(p)], [cu(q)], beta, soft=True, codes=True, sumsq=True)
+    assert_bits_equal(out["W"][0].cpu().numpy(), ref["W"], "W")
+    assert np.array_equal(out["idx"][0].cpu().numpy().astype(np.int32), ref["idx"])
+    assert_bits_equal(out["W_hard"][0].cpu().numpy(), ref["W_hard"], "W_hard")
+    ss = float(out["sumsq"].cpu()[0])
+    assert abs(ss - ref["sumsq"]) <= 2e-5 * ref["sumsq"] + 1e-30
+    # soft-only launch (the training path) gives the same W
+    out2 = ops.synth_forward([cu(p)], [cu(q)], beta, soft=True, codes=False, sumsq=False)
+    assert_bits_equal(out2["W"][0].cpu().numpy(), ref["W"], "W(soft only)")
+
+
+def test_synth_forward_reference_fixtures(golden):
+    """Same inputs as the reference run: codes equal to the reference's wherever the reference's own
+    arg-max was not decided by fp32 rounding; W within fp32 tolerance of the reference."""
+    g = golden("synth")
+    for c in range(int(g["ncase"])):
+        k = "c%02d_" % c
+        beta = float(g[k + "meta"][2])
+        p, q = g[k + "p_c"], g[k + "q"]
+        out = ops.synth_forward([cu(p)], [cu(q)], beta, soft=True, codes=True)
+        W = out["W"][0].cpu().numpy()
+        idx = out["idx"][0].cpu().numpy()
+        ref = O.synth_fwd(p, q, beta)
+        assert_bits_equal(W, ref["W"], "W case %d" % c)
+        assert np.array_equal(idx.astype(np.int32), ref["idx"])
+        flag = g[k + "rounding_tie"]
+        assert np.all((idx == g[k + "idx"]) | flag)
+        ok = ~np.isnan(g[k + "W"])
+        assert np.all(np.abs(W[ok] - g[k + "W"][ok]) <= 1e-6 * np.abs(q).max() + 2e-6 * np.abs(g[k + "W"][ok]))
+        assert np.array_equal(np.isnan(W), np.isnan(g[k + "W"]))
+
+
+@pytest.mark.parametrize("L", [4, 31, 32, 33, 64, 100])
+@pytest.mark.parametrize("rows", [1, 63, 64, 300, 4099])
+def test_synth_backward_bit_exact_dp(L, rows):
+    rs = np.random.RandomState(L * 7919 + rows)
+    p = rs.random_sample((rows, L)).astype(np.float32)
+    q = rand_levels(rs, L)
+    dW = rs.standard_normal(rows).astype(np.float32)
+    beta, wd = 2.0, 1e-3
+    dp_ref, dq_ref = O.synth_bwd(p, q, beta, dW, wd)
+    dp, dq = ops.synth_backward([cu(p)], [cu(q)], beta, [cu(dW)], wd)
+    assert_bits_equal(dp[0].cpu().numpy(), dp_ref, "dp_c")
+    got = dq[0].cpu().numpy().astype(np.float64)
+    assert np.abs(got - dq_ref).max() <= 2e-5 * np.abs(dq_ref).max() + 1e-12
+    # dW = None (regulariser only) and frozen levels (no dq)
+    dp_ref, _ = O.synth_bwd(p, q, beta, None, wd)
+    dp, dq = ops.synth_backward([cu(p)], [cu(q)], beta, [None], wd, need_dq=[False])
+    assert dq[0] is None
+    assert_bits_equal(dp[0].cpu().numpy(), dp_ref, "dp_c(reg only)")
+
+
+def test_synth_multi_segment_resnet20_shapes():
+    """All 19 quantized layers of ResNet-20 (fix: L=31, others L=32, mixed) in one call."""
+    rs = np.random.RandomState(5)
+    shapes = [(16, 16)] * 6 + [(32, 16)] + [(32, 32)] * 5 + [(64, 32)] + [(64, 64)] * 5
+    ps, qs, Ls = [], [], []
+    for i, (co, ci) in enumerate(shapes):
+        L = 31 if i % 3 == 0 else 32
+        ps.append(rs.random_sample((co, ci, 3, 3, L)).astype(np.float32))
+        qs.append(hint_levels(L, 0.1 + 0.05 * i))
+        Ls.append(L)
+    ps.append(rs.random_sample((64, 10, 32)).astype(np.float32))
+    qs.append(hint_levels(32, 0.9))
+    beta = 3.0
+    out = ops.synth_forward([cu(p) for p in ps], [cu(q) for q in qs], beta, soft=True, codes=True, sumsq=True)
+    dWs = [rs.standard_normal(p.shape[:-1]).astype(np.float32) for p in ps]
+    need = [i % 2 == 0 for i in range(len(ps))]
+    dps, dqs = ops.synth_backward([cu(p) for p in ps], [cu(q) for q in qs], beta, [cu(d) for d in dWs], 1e-3, need_dq=need)
+    ss = out["sumsq"].cpu().numpy()
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        ref = O.synth_fwd(p, q, beta)
+        assert out["W"][i].shape == p.shape[:-1]
+        assert_bits_equal(out["W"][i].cpu().numpy(), ref["W"], "W[%d]" % i)
+        assert np.array_equal(out["idx"][i].cpu().numpy().astype(np.int32), ref["idx"])
+        assert abs(ss[i] - ref["sumsq"]) <= 2e-5 * ref["sumsq"]
+        dp_ref, dq_ref = O.synth_bwd(p, q, beta, dWs[i], 1e-3)
+        assert_bits_equal(dps[i].cpu().numpy(), dp_ref, "dp[%d]" % i)
+        if need[i]:
+            assert np.abs(dqs[i].cpu().numpy() - dq_ref).max() <= 2e-5 * np.abs(dq_ref).max()
+        else:
+            assert dqs[i] is None
+
+
+def test_synth_is_run_to_run_deterministic_and_handles_empty():
+    rs = np.random.RandomState(3)
+    p, q = cu(rs.random_sample((70001, 32)).astype(np.float32)), cu(hint_levels(32))
+    dW = cu(rs.standard_normal(70001).astype(np.float32))
+    a = ops.synth_forward([p], [q], 4.0, sumsq=True)
+    b = ops.synth_forward([p], [q], 4.0, sumsq=True)
+    assert torch.equal(a["sumsq"], b["sumsq"]) and torch.equal(a["W"][0], b["W"][0])
+    d1 = ops.synth_backward([p], [q], 4.0, [dW], 0.0)
+    d2 = ops.synth_backward([p], [q], 4.0, [dW], 0.0)
+    assert torch.equal(d1[1][0], d2[1][0]) and torch.equal(d1[0][0], d2[0][0])
+    e = ops.synth_forward([p[:0]], [q], 1.0, sumsq=True)
+    assert e["W"][0].numel() == 0 and float(e["sumsq"][0]) == 0.0
+    with pytest.raises(RuntimeError, match="beta"):
+        ops.synth_forward([p], [q], 1e3)
+    with pytest.raises(ValueError):
+        ops.synth_forward([p], [q[:5]], 1.0)
+    with pytest.raises(ValueError):
+        ops.synth_forward([p.double()], [q], 1.0)
+
+
+CONV_SHAPES = [  # cin, cout, stride, H, W, N
+    (16, 16, 1, 32, 32, 2), (16, 32, 2, 32, 32, 2), (32, 32, 1, 16, 16, 3), (32, 64, 2, 16, 16, 2), (64, 64, 1, 8, 8, 5),
+    (3, 7, 1, 5, 5, 2), (5, 3, 2, 6, 6, 2), (16, 16, 1, 9, 9, 1), (16, 32, 2, 9, 9, 1), (64, 64, 1, 4, 4, 1),
+    (17, 33, 1, 13, 7, 2), (33, 17, 2, 11, 20, 3), (1, 1, 1, 1, 1, 1), (4, 4, 2, 1, 1, 1), (8, 80, 1, 40, 36, 1),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_forward_dgrad_wgrad_vs_oracle(shape):
+    cin, cout, stride, H, Wd, N = shape
+    rs = np.random.RandomState(sum(shape) * 31 + H)
+    x = rs.standard_normal((N, cin, H, Wd)).astype(np.float32)
+    W = (rs.standard_normal((cout, cin, 3, 3)) * 0.2).astype(np.float32)
+    y_ref = O.conv_fwd(x, W, stride, 1)
+    y = ops.conv_forward(cu(x), cu(W), stride).cpu().numpy()
+    assert y.shape == y_ref.shape
+    assert np.abs(y - y_ref).max() <= 2e-5 * np.abs(y_ref).max() + 1e-30
+    dy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv_dgrad(dy, W, x.shape, stride, 1)
+    dx = ops.conv_dgrad(cu(dy), cu(W), x.shape, stride).cpu().numpy()
+    assert np.abs(dx - dx_ref).max() <= 2e-5 * np.abs(dx_ref).max() + 1e-30
+    dW_ref = O.conv_wgrad(x, dy, 3, stride, 1)
+    dW = ops.conv_wgrad(cu(x), cu(dy), stride).cpu().numpy()
+    assert np.abs(dW - dW_ref).max() <= 2e-5 * np.abs(dW_ref).max() + 1e-30
+
+
+def test_conv_asymmetric_identity_probe():
+    """One-hot weights and ramp inputs: catches transposed fragments / swapped taps exactly."""
+    cin, cout, H = 16, 16, 8
+    x = np.arange(2 * cin * H * H, dtype=np.float32).reshape(2, cin, H, H) / 7.0
+    for tap in range(9):
+        W = np.zeros((cout, cin, 3, 3), np.float32)
+        for co in range(cout):
+            W[co, (co * 5 + 3) % cin, tap // 3, tap % 3] = 1.0
+        y = ops.conv_forward(cu(x), cu(W), 1).cpu().numpy()
+        assert np.array_equal(y, O.conv_fwd(x, W, 1, 1)), tap
+
+
+def test_conv_reference_fixtures(golden):
+    g = golden("conv")
+    for c in range(int(g["ncase"])):
+        k = "c%02d_" % c
+        cin, cout, stride, H, N = [int(v) for v in g[k + "shape"]]
+        x, W, dy = cu(g[k + "x"]), cu(g[k + "W"]), cu(g[k + "dy"])
+        y = ops.conv_forward(x, W, stride).cpu().numpy()
+        assert np.abs(y - g[k + "y"]).max() <= 2e-5 * np.abs(g[k + "y"]).max()
+        dx = ops.conv_dgrad(dy, W, x.shape, stride).cpu().numpy()
+        assert np.abs(dx - g[k + "dx"]).max() <= 2e-5 * np.abs(g[k + "dx"]).max()
+        dW = ops.conv_wgrad(x, dy, stride).cpu().numpy()
+        assert np.abs(dW - g[k + "dW"]).max() <= 2e-5 * np.abs(g[k + "dW"]).max()
+
+
+def test_conv_codes_equals_conv_of_decoded_weights():
+    rs = np.random.RandomState(8)
+    for (cin, cout, stride, H) in [(16, 32, 2, 16), (32, 32, 1, 8), (5, 3, 1, 6)]:
+        L = 31
+        q = O.levels_fix(0.4, 32)
+        idx = rs.randint(0, L, (cout, cin, 3, 3)).astype(np.uint8)
+        x = rs.standard_normal((2, cin, H, H)).astype(np.float32)
+        y = ops.conv_forward_codes(cu(x), cu(idx, torch.uint8), cu(q), stride)
+        y2 = ops.conv_forward(cu(x), cu(q[idx]), stride)
+        assert torch.equal(y, y2)
+
+
+def test_conv_full_batch_linearity_and_determinism():
+    """BASELINE-size layer (batch 128): conv(a*x1 + x2) == a*conv(x1) + conv(x2) within fp32, wgrad reproducible."""
+    torch.manual_seed(0)
+    for (cin, cout, stride, H) in [(16, 16, 1, 32), (32, 64, 2, 16), (64, 64, 1, 8)]:
+        x1 = torch.randn(128, cin, H, H, device=DEV)
+        x2 = torch.randn(128, cin, H, H, device=DEV)
+        W = torch.randn(cout, cin, 3, 3, device=DEV) * 0.1
+        y = ops.conv_forward(2.0 * x1 + x2, W, stride)
+        y12 = 2.0 * ops.conv_forward(x1, W, stride) + ops.conv_forward(x2, W, stride)
+        assert (y - y12).abs().max() <= 2e-5 * y.abs().max()
+        dy = torch.randn_like(y)
+        a, b = ops.conv_wgrad(x1, dy, stride), ops.conv_wgrad(x1, dy, stride)
+        assert torch.equal(a, b)
+        # <dy, conv(x)> == <dgrad(dy), x> == <wgrad(x, dy), W>   (adjoint identities)
+        lhs = (dy.double() * ops.conv_forward(x1, W, stride).double()).sum()
+        mid = (ops.conv_dgrad(dy, W, x1.shape, stride).double() * x1.double()).sum()
+        rhs = (a.double() * W.double()).sum()
+        assert abs(lhs - mid) <= 1e-5 * abs(lhs) + 1e-3 and abs(lhs - rhs) <= 1e-5 * abs(lhs) + 1e-3
+
+
+def test_linear_vs_oracle_and_fixture(golden):
+    g = golden("linear")
+    for c in range(int(g["ncase"])):
+        k = "c%02d_" % c
+        x, W, b, gy = g[k + "x"], g[k + "W"], g[k + "bias"], g[k + "g"]
+        y = ops.linear_forward(cu(x), cu(W), cu(b)).cpu().numpy()
+        assert np.abs(y - g[k + "y"]).max() <= 1e-5 * np.abs(g[k + "y"]).max()
+        dx, dW, db = ops.linear_backward(cu(x), cu(W), cu(gy))
+        assert np.abs(dx.cpu().numpy() - g[k + "dx"]).max() <= 1e-5 * np.abs(g[k + "dx"]).max()
+        assert np.abs(dW.cpu().numpy() - g[k + "dW"]).max() <= 1e-5 * np.abs(g[k + "dW"]).max()
+        assert np.abs(db.cpu().numpy() - g[k + "dbias"]).max() <= 1e-5 * np.abs(g[k + "dbias"]).max()

@@ -154,9 +154,8 @@ def test_level_initialisers_match_reference(golden):
 
 
 def test_expf_accuracy():
-    x = np.linspace(-20, 20, 20001).astype(np.float32)
+    x = np.linspace(-64, 64, 20001).astype(np.float32)
     got = O.expf(x).astype(np.float64)
     ref = np.exp(x.astype(np.float64))
     assert np.max(np.abs(got - ref) / ref) < 1.3e-7
-    assert O.expf(np.float32(100.0)) == np.inf and O.expf(np.float32(-200.0)) == 0.0
     assert np.isnan(O.expf(np.float32(np.nan)))
