@@ -40,6 +40,8 @@ typedef struct aq_seg {
     float *sumsq;       /* [1]    sum_rows W^2, the layer's term of model_loss (fan.py:752)  */
     /* backward inputs / outputs */
     const float *dW;    /* [rows] d loss / d W (NULL = zero)                                 */
+    const float *dsumsq;/* [1]    d loss / d sumsq on the device (NULL = zero); the kernel adds
+                                  2*dsumsq[0] to wd, so no host read-back is needed            */
     float *dp_c;        /* [rows, L] d loss / d p_c                                          */
     float *dq;          /* [L]    d loss / d q_level (NULL for frozen levels, fix.py:652)    */
 } aq_seg;

@@ -25,7 +25,7 @@ class AqSeg(C.Structure):
     _fields_ = [
         ("p_c", C.c_void_p), ("q", C.c_void_p), ("rows", C.c_int64), ("L", C.c_int32), ("reserved", C.c_int32),
         ("W", C.c_void_p), ("idx", C.c_void_p), ("W_hard", C.c_void_p), ("sumsq", C.c_void_p),
-        ("dW", C.c_void_p), ("dp_c", C.c_void_p), ("dq", C.c_void_p),
+        ("dW", C.c_void_p), ("dsumsq", C.c_void_p), ("dp_c", C.c_void_p), ("dq", C.c_void_p),
     ]
 
 

@@ -31,7 +31,7 @@ constexpr int WAVES = 4;      // wavefronts per workgroup
 constexpr int ROWS_IT = 64;   // rows per wavefront iteration
 
 struct SegDev {
-    const float *p, *q, *dW;
+    const float *p, *q, *dW, *dss;
     float *W, *Wh, *dp, *part;
     uint8_t *idx;
     long long rows;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     const float *__restrict__ q = tab.s[si].q;
     const float *__restrict__ dW = tab.s[si].dW;
     float *__restrict__ dp = tab.s[si].dp;
+    const float wds = tab.s[si].dss ? __builtin_fmaf(2.0f, tab.s[si].dss[0], wd) : wd;
     float *__restrict__ part = tab.s[si].part;
     const long long rows = tab.s[si].rows;
     const int L = tab.s[si].L;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                 const float num = group_sum<G>(chain_dot(e, q4));
                 const float rden = 1.0f / den;
                 const float w = num * rden;
-                const float g = __builtin_fmaf(wd, w, gw[u]);
+                const float g = __builtin_fmaf(wds, w, gw[u]);
                 const float dot = g * w;
                 float s[4], gpn[4];
 #pragma unroll
@@ -421,7 +422,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspa
                 if (BWD) v = v && (((uintptr_t)s.dp_c & 15) == 0);
                 if ((int)v != vec) continue;
                 SegDev &d = tab.s[tab.nseg];
-                d.p = s.p_c; d.q = s.q; d.dW = s.dW; d.W = s.W; d.Wh = s.W_hard; d.dp = s.dp_c; d.idx = s.idx;
+                d.p = s.p_c; d.q = s.q; d.dW = s.dW; d.dss = s.dsumsq; d.W = s.W; d.Wh = s.W_hard; d.dp = s.dp_c; d.idx = s.idx;
                 const bool need = BWD ? s.dq != nullptr : s.sumsq != nullptr;
                 d.part = need ? reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.off[i]) : nullptr;
                 d.rows = s.rows; d.L = s.L; d.blk0 = nblocks;

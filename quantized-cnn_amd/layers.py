@@ -1,0 +1,327 @@
+"""Quantized layers with the reference scripts' module API, running on the HIP kernels.
+
+Shared implementation behind `adp_qtz_fan`, `adp_qtz_fix` and `adp_qtz_hint` (which expose the
+reference's class names and constructor signatures).  What is kept from the reference:
+  * parameters `p_c` (..., L), `q_level` (L,), `bias`; state_dict keys; `mode` taken from
+    `config.mode` at construction ("train" = soft weights, "test" = hard codes) and not changed
+    by `.eval()`                                                   (adp_qtz_fan.py:533-549)
+  * the sharpening factor `beta` read at call time from the variant module's global
+    (`adp_qtz_fan.beta = 2`), or from an explicit `layer.beta` attribute when set
+  * `model_loss(config, beta, model)`                              (adp_qtz_fan.py:737-754)
+What changes: the synthesis of all layers of a ResNet runs as ONE segmented kernel launch per
+step, shared by the forward pass and by model_loss, and its backward is ONE launch that receives
+the convolution weight gradients through a flat buffer (which is also what data-parallel training
+all-reduces).  There is no CPU path: calling a layer with CPU tensors raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# Hook for data-parallel training: called in the synthesis backward with the flat buffer that
+# holds d loss/d W of all quantized layers, before it is turned into dp_c / dq.  `train.DataParallel`
+# installs an all-reduce here.
+_dW_reduce_hook = None
+
+
+def set_dW_reduce_hook(fn):
+    global _dW_reduce_hook
+    _dW_reduce_hook = fn
+
+
+# ---------------------------------------------------------------------------------------- autograd
+
+class _SynthAll(torch.autograd.Function):
+    """(p_0, q_0, p_1, q_1, ..) -> (W_0, W_1, .., sumsq[n]).  W_i are views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, beta, holder, *params):
+        ps, qs = params[0::2], params[1::2]
+        dev = ps[0].device
+        sizes = [p.numel() // p.shape[-1] for p in ps]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        Ws, off = [], 0
+        for p, n in zip(ps, sizes):
+            Ws.append(flat[off:off + n].view(p.shape[:-1]))
+            off += n
+        out = ops.synth_forward(list(ps), list(qs), beta, soft=True, sumsq=True, out_W=Ws)
+        ctx.save_for_backward(*params)
+        ctx.beta, ctx.sizes = beta, sizes
+        # the flat gradient buffer the conv / linear backward kernels write into
+        dflat = torch.empty_like(flat)
+        slots, off = [], 0
+        for p, n in zip(ps, sizes):
+            slots.append(dflat[off:off + n].view(p.shape[:-1]))
+            off += n
+        ctx.dflat, ctx.slots = dflat, slots
+        if holder is not None:
+            holder["slots"] = slots
+        return (*Ws, out["sumsq"])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        params = ctx.saved_tensors
+        ps, qs = params[0::2], params[1::2]
+        n = len(ps)
+        gW, gss = grads[:n], grads[n]
+        dW = []
+        for g, slot in zip(gW, ctx.slots):
+            if g is None:
+                dW.append(None)
+            elif g.data_ptr() == slot.data_ptr() and g.is_contiguous():
+                dW.append(slot)
+            else:
+                slot.copy_(g)
+                dW.append(slot)
+        if _dW_reduce_hook is not None:
+            for i, d in enumerate(dW):
+                if d is None:
+                    ctx.slots[i].zero_()
+                    dW[i] = ctx.slots[i]
+            _dW_reduce_hook(ctx.dflat)
+        need_dq = [q.requires_grad for q in qs]
+        dss = gss.contiguous() if gss is not None else None
+        dp, dq = ops.synth_backward(list(ps), list(qs), ctx.beta, dW, 0.0, need_dq=need_dq, dsumsq=dss)
+        out = [None, None]
+        for i in range(n):
+            out.append(dp[i] if ps[i].requires_grad else None)
+            out.append(dq[i])
+        return tuple(out)
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, stride, dW_slot):
+        x = x.contiguous()
+        ctx.save_for_backward(x, W)
+        ctx.stride, ctx.dW_slot = stride, dW_slot
+        return ops.conv_forward(x, W, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
+        dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot) if ctx.needs_input_grad[1] else None
+        return dx, dW, None, None
+
+
+class _LinearIO(torch.autograd.Function):
+    """y = x @ W + bias with W stored (in, out)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, dW_slot):
+        x = x.contiguous()
+        ctx.save_for_backward(x, W)
+        ctx.dW_slot = dW_slot
+        return ops.linear_forward(x, W.contiguous(), bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx, dW, db = ops.linear_backward(x, W.contiguous(), dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        if ctx.dW_slot is not None:
+            ctx.dW_slot.copy_(dW)
+            dW = ctx.dW_slot
+        return dx, dW, db, None
+
+
+# ------------------------------------------------------------------------------------------ layers
+
+def _levels_pow2(s, num_level, with_zero, liar=True):
+    """fix (with_zero): adp_qtz_fix.py:661-665; hint: adp_qtz_hint.py:657-662."""
+    t2 = math.floor(math.log(s, 2)) if liar else round(math.log(s, 2))
+    t3 = torch.arange(t2 - num_level / 2 + (2 if with_zero else 1), t2 + 1)
+    pos = 2 ** t3
+    parts = [(-pos).sort()[0], torch.zeros(1), pos] if with_zero else [(-pos).sort()[0], pos]
+    return torch.cat(parts).to(torch.float32)
+
+
+class _QuantBase(nn.Module):
+    """Common part of MyConv2d / MyLinear: parameters, level initialisation, weight synthesis."""
+    variant = "fan"
+    beta = None  # explicit per-layer override of the module-global sharpening factor
+
+    def _global_beta(self):
+        raise NotImplementedError  # bound by the variant module (reads its module-level `beta`)
+
+    def current_beta(self):
+        return float(self.beta if self.beta is not None else self._global_beta())
+
+    def _make_params(self, config, shape, num_level):
+        L = num_level - 1 if self.variant == "fix" else num_level
+        if config.prim_init == "uniform":
+            self.p_c = nn.Parameter(torch.rand(tuple(shape) + (L,)), requires_grad=True)
+        elif config.prim_init == "normal":
+            self.p_c = nn.Parameter(torch.randn(tuple(shape) + (L,)), requires_grad=True)
+        else:
+            raise ValueError("Unknown prim_init \"{}\"".format(config.prim_init))
+        self.q_level = nn.Parameter(torch.empty(L), requires_grad=self.variant != "fix")
+        self.mode = config.mode
+        self._shared = None  # (W, dW_slot) handed down by the owning ResNet for the current step
+
+    def _init_levels(self, config, num_level, fan_in, s):
+        with torch.no_grad():
+            if self.variant == "fan":
+                gain = math.sqrt(2.0 / (1 + math.sqrt(5) ** 2))
+                bound = math.sqrt(3.0) * gain / math.sqrt(fan_in)
+                self.q_level.uniform_(-bound, bound)
+            elif self.variant == "fix":
+                self.q_level.copy_(_levels_pow2(s, num_level, True, bool(getattr(config, "liar", True))))
+            else:
+                self.q_level.copy_(_levels_pow2(s, num_level, False))
+
+    def synthesize(self):
+        """-> (W, dW_slot) in soft mode, (idx, None) in hard mode."""
+        if self.mode == "train":
+            if self._shared is not None:
+                sh, self._shared = self._shared, None
+                return sh
+            holder = {}
+            W, _ = _SynthAll.apply(self.current_beta(), holder, self.p_c, self.q_level)
+            return W, holder["slots"][0]
+        if self.mode == "test":
+            out = ops.synth_forward([self.p_c.detach()], [self.q_level.detach()], self.current_beta(), soft=False, codes=True)
+            return out, None
+        raise ValueError("Unknown run mode \"{}\"".format(self.mode))
+
+
+class QConv2d(_QuantBase):
+    def _setup(self, config, s, in_channel, out_channel, ksize, stride, padding):
+        self._make_params(config, (out_channel, in_channel, ksize, ksize), config.num_level_conv)
+        self.ksize, self.stride, self.padding = ksize, stride, padding
+        self._init_levels(config, config.num_level_conv, in_channel * ksize * ksize, s)
+
+    def forward(self, x):
+        assert len(x.shape) == 4
+        if self.ksize != 3 or self.padding != 1 or self.stride not in (1, 2):
+            raise NotImplementedError("the HIP convolution implements ksize=3, padding=1, stride 1|2 "
+                                      "(got ksize=%d padding=%d stride=%d)" % (self.ksize, self.padding, self.stride))
+        w, slot = self.synthesize()
+        if self.mode == "train":
+            return _Conv3x3.apply(x, w, self.stride, slot)
+        return ops.conv_forward_codes(x.contiguous(), w["idx"][0], self.q_level.detach(), self.stride)
+
+
+class QLinear(_QuantBase):
+    def _setup(self, config, s, v, in_feature, out_feature):
+        self._make_params(config, (in_feature, out_feature), config.num_level_fc)
+        self.bias = nn.Parameter(torch.empty(out_feature), requires_grad=True)
+        self._init_levels(config, config.num_level_fc, in_feature, s)
+        with torch.no_grad():
+            if self.variant == "fan":
+                bound = 1 / math.sqrt(in_feature)
+                self.bias.uniform_(-bound, bound)
+            else:
+                self.bias.copy_(v.detach().reshape(-1))
+
+    def forward(self, x):
+        assert len(x.shape) == 2
+        w, slot = self.synthesize()
+        if self.mode == "train":
+            return _LinearIO.apply(x, w, self.bias, slot)
+        return ops.linear_forward(x.contiguous(), w["W_hard"][0], self.bias.detach())
+
+
+class _Block(nn.Module):
+    def _shortcut(self, in_channel, increase_dim):
+        if not increase_dim:
+            return nn.Identity()
+        return nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0, in_channel // 2, in_channel // 2)))
+
+
+class QResNet(nn.Module):
+    """ResNet-20 body shared by the variants (adp_qtz_fan.py:696-734).  Subclasses build conv0, bn0,
+    layer1..3, bnlast, ap, linear with the reference's attribute names."""
+
+    def quant_layers(self):
+        return [m for m in self.modules() if isinstance(m, _QuantBase)]
+
+    def _synthesize_all(self):
+        """One segmented launch for every quantized layer; hands (W, dW slot) to each layer and keeps
+        the per-layer sum W^2 for model_loss."""
+        layers = self.quant_layers()
+        self._synth_cache = None
+        if not layers or layers[0].mode != "train":
+            return
+        beta = layers[0].current_beta()
+        if any(l.current_beta() != beta for l in layers):
+            return  # per-layer betas: every layer synthesises on its own
+        params = []
+        for l in layers:
+            params += [l.p_c, l.q_level]
+        holder = {}
+        outs = _SynthAll.apply(beta, holder, *params)
+        for l, W, slot in zip(layers, outs[:-1], holder["slots"]):
+            l._shared = (W, slot)
+        self._synth_cache = {"beta": beta, "sumsq": outs[-1], "versions": [p._version for p in params],
+                             "grad": torch.is_grad_enabled()}
+
+    def cached_sumsq(self, beta):
+        c = getattr(self, "_synth_cache", None)
+        if c is None or c["beta"] != float(beta) or c["grad"] != torch.is_grad_enabled():
+            return None
+        params = []
+        for l in self.quant_layers():
+            params += [l.p_c, l.q_level]
+        if [p._version for p in params] != c["versions"]:
+            return None
+        self._synth_cache = None  # one use per forward
+        return c["sumsq"]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
+        self._synthesize_all()
+        out = F.relu(self.bn0(self.conv0(x)))
+        out = self.layer1(out)
+        out = self.layer2(out)
+        out = self.layer3(out)
+        out = F.relu(self.bnlast(out))
+        out = self.ap(out)
+        out = out.view(out.size(0), -1)
+        out = self.linear(out)
+        return out
+
+
+def model_loss(config, beta, model):
+    """l2_reg * ( sum over parameters whose name contains "weight" of sum p^2
+                  + sum over quantized layers of sum W^2 )          (adp_qtz_fan.py:737-754).
+    The quantized term reuses the synthesis of the preceding model.forward() when parameters and
+    beta are unchanged; otherwise it runs the segmented synthesis kernel again."""
+    dense, pairs, p_c = [], [], None
+    for name, param in model.named_parameters():
+        if "weight" in name:
+            dense.append(param)
+        if "p_c" in name:
+            p_c = param
+        if "q_level" in name:
+            pairs.append((p_c, param))
+    loss = 0
+    if dense:
+        loss = loss + torch.cat([d.reshape(-1) for d in dense]).pow(2).sum()
+    if pairs:
+        ss = model.cached_sumsq(beta) if hasattr(model, "cached_sumsq") else None
+        if ss is None or ss.numel() != len(pairs):
+            params = []
+            for p, q in pairs:
+                params += [p, q]
+            ss = _SynthAll.apply(float(beta), None, *params)[-1]
+        loss = loss + ss.sum()
+    return config.l2_reg * loss
+
+
+def scales_from_baseline(model_b):
+    """max|W| of the 19 conv + 1 linear weights of a trained full-precision ResNet-20 and its
+    linear bias (adp_qtz_fix.py:208-215, adp_qtz_hint.py:204-211)."""
+    s, v = [], None
+    for name, param in model_b.named_parameters():
+        if ("conv" in name and "weight" in name) or ("linear" in name and "weight" in name):
+            s.append(torch.max(torch.abs(param)).item())
+        elif "linear" in name and "bias" in name:
+            v = param
+    assert len(s) == 20
+    return s, v

@@ -71,11 +71,13 @@ def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out
     return out
 
 
-def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None):
+def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None, dsumsq=None):
     """Gradient of the synthesis for several layers in one launch.
 
     dW_list[i]: upstream d loss/d W (shape p.shape[:-1]) or None; wd = 2*l2_reg*(d loss/d reg).
-    need_dq[i] False skips dq (frozen levels).  Returns (dp_list, dq_list) with None where skipped.
+    need_dq[i] False skips dq (frozen levels).  dsumsq: optional fp32 device tensor [n] with
+    d loss/d sumsq per layer (adds 2*dsumsq[i] to wd on the device, no host read-back).
+    Returns (dp_list, dq_list) with None where skipped.
     """
     n = len(p_list)
     segs = _seg_array(p_list, q_list)
@@ -89,6 +91,8 @@ def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=N
                 raise ValueError("dW[%d] has %d elements, expected %d" % (i, dW_list[i].numel(), segs[i].rows))
             segs[i].dW = _lib.ptr(dW_list[i], name="dW[%d]" % i)
         segs[i].dp_c = _lib.ptr(dp[i], name="dp_c[%d]" % i)
+        if dsumsq is not None:
+            segs[i].dsumsq = _lib.ptr(dsumsq, name="dsumsq") + 4 * i
         if dq[i] is not None:
             segs[i].dq = _lib.ptr(dq[i], name="dq[%d]" % i)
     ws, nbytes = _workspace(segs, n, True, dev)

@@ -1,0 +1,170 @@
+"""Training step of the quantized ResNet: the loop body of the reference's `train()`
+(adp_qtz_fan.py:280-297) as a reusable object, with optional HIP-graph capture of the whole step
+and optional data parallelism (one process per GPU, RCCL through torch.distributed).
+
+    step = TrainStep(model, config, module)        # module: adp_qtz_fan / _fix / _hint (owns `beta`)
+    loss = step(x, y)                              # fwd + CE + model_loss + bwd + 3x Adam + zero_grad
+
+Data parallelism (pure DP, parameters replicated, batch sharded):
+  * d loss/d W of all quantized layers lives in one flat buffer (1.07 MB for ResNet-20) that is
+    all-reduced ONCE inside the backward pass, before the synthesis-gradient kernel turns it into
+    dp_c (34 MB) and dq on every rank.  dp_c/dq are linear in dW with a Jacobian that depends only on
+    replicated parameters, so this equals all-reducing dp_c at 1/32 of the bytes.
+  * gradients of the remaining (dense) parameters - conv0, BatchNorm, linear.bias - are
+    all-reduced as a second small flat buffer after backward.
+  * the regulariser's gradient is added locally on every rank (it does not depend on the batch).
+  * BatchNorm statistics are per replica unless `sync_bn=True` converts the model to SyncBatchNorm.
+"""
+import torch
+import torch.nn as nn
+
+from . import layers
+
+
+def split_parameters(model):
+    """The reference's three optimizer groups, selected by parameter name (adp_qtz_fan.py:208-213)."""
+    named = list(model.named_parameters())
+    prim = [p for n, p in named if "p_c" in n]
+    qlev = [p for n, p in named if "q_level" in n]
+    rest = [p for n, p in named if "p_c" not in n and "q_level" not in n]
+    return prim, qlev, rest
+
+
+def make_optimizers(model, config, capturable=False):
+    prim, qlev, rest = split_parameters(model)
+    kw = dict(capturable=True) if capturable else {}
+    # q_level of the `fix` variant has requires_grad=False: Adam skips parameters without grad
+    return (torch.optim.Adam(prim, lr=getattr(config, "prim_lr", 1e-2), **kw),
+            torch.optim.Adam(qlev, lr=getattr(config, "q_lr", 1e-3), **kw),
+            torch.optim.Adam(rest, lr=getattr(config, "lr", 1e-2), **kw))
+
+
+class DataParallel:
+    """Gradient exchange for pure data parallelism over torch.distributed (backend "nccl" = RCCL on
+    ROCm, "gloo" on CPU for tests).  Installs the flat-dW all-reduce hook of `layers`."""
+
+    def __init__(self, model, process_group=None, sync_bn=False):
+        import torch.distributed as dist
+        self.dist, self.group = dist, process_group
+        self.world = dist.get_world_size(process_group)
+        self.model = model
+        if sync_bn and self.world > 1:
+            nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group)
+        _, _, rest = split_parameters(model)
+        self.dense = [p for p in rest if p.requires_grad]
+        layers.set_dW_reduce_hook(self.reduce_flat if self.world > 1 else None)
+        # identical initial parameters on every rank
+        if self.world > 1:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0, group=process_group)
+
+    def reduce_flat(self, flat):
+        self.dist.all_reduce(flat, group=self.group)
+        flat.div_(self.world)
+
+    def reduce_dense(self):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.dense if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self.reduce_flat(flat)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def close(self):
+        layers.set_dW_reduce_hook(None)
+
+
+class TrainStep:
+    """One optimisation step with the reference's order of operations: forward, CrossEntropy +
+    model_loss, backward, optimizer_prim / optimizer_q / optimizer .step(), three zero_grad()."""
+
+    def __init__(self, model, config, module, dp=None, use_graph=False):
+        self.model, self.config, self.module, self.dp = model, config, module, dp
+        self.criterion = nn.CrossEntropyLoss()
+        self.use_graph = use_graph
+        self.opts = make_optimizers(model, config, capturable=use_graph)
+        self._graph = None
+        self._key = None
+
+    # -- eager ---------------------------------------------------------------------------------
+    def _body(self, x, y):
+        logits = self.model.forward(x)
+        loss = self.criterion(logits, y) + self.module.model_loss(self.config, self.module.beta, self.model)
+        loss.backward()
+        if self.dp is not None:
+            self.dp.reduce_dense()
+        for o in self.opts:
+            o.step()
+        return loss, logits
+
+    def __call__(self, x, y):
+        if not self.use_graph:
+            loss, logits = self._body(x, y)
+            for o in self.opts:
+                o.zero_grad()
+            self.logits = logits.detach()
+            return loss.detach()
+        return self._graph_step(x, y)
+
+    # -- whole step captured in one HIP graph ----------------------------------------------------
+    def _graph_step(self, x, y):
+        key = (tuple(x.shape), float(self.module.beta), tuple(g["lr"] for o in self.opts for g in o.param_groups))
+        if self._graph is None or key != self._key:
+            self._capture(x, y)
+            self._key = key
+        self._sx.copy_(x)
+        self._sy.copy_(y)
+        self._graph.replay()
+        self.logits = self._slogits
+        return self._sloss
+
+    def _capture(self, x, y):
+        """Parameters and optimizer state are updated by the warm-up iterations, exactly as eager
+        steps would; afterwards every replay is one more step."""
+        if self.dp is not None and self.dp.world > 1:
+            raise RuntimeError("graph capture of the data-parallel step is not supported; use use_graph=False")
+        self._sx, self._sy = x.clone(), y.clone()
+        self._graph = None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for o in self.opts:
+                o.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            # capture without a warm-up step so that step counts stay those of the reference loop;
+            # Adam state is created lazily on the first step, so initialise it first (no update)
+            for o in self.opts:
+                for group in o.param_groups:
+                    for p in group["params"]:
+                        if p.requires_grad and len(o.state[p]) == 0:
+                            o.state[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                            o.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                            o.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                loss, logits = self._body(self._sx, self._sy)
+                self._sloss, self._slogits = loss.detach(), logits.detach()
+                for o in self.opts:
+                    o.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph = g
+
+
+def beta_schedule(config, epoch, beta, opts):
+    """Per-epoch schedule of the reference (adp_qtz_fan.py:269-278): beta steps at epoch_list[1..3],
+    learning rates divided by 5 at epoch_list[4].  Returns the new beta."""
+    beta_list = list(map(int, config.beta_list.strip("[]").split(",")))
+    epoch_list = list(map(int, config.epoch_list.strip("[]").split(",")))
+    for k in (1, 2, 3):
+        if epoch == epoch_list[k]:
+            beta = beta_list[k]
+    if epoch == epoch_list[4]:
+        for o in opts:
+            o.param_groups[0]["lr"] /= 5
+    return beta

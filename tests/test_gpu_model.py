@@ -1,0 +1,156 @@
+"""Whole-model parity on the GPU against the reference run recorded in tests/golden/train.npz:
+same initial parameters (numpy RandomState stream), same batch, five optimisation steps
+(fwd + CE + model_loss + bwd + 3x Adam) with a beta change at step 3.
+
+Tolerances (fp32, different reduction orders over ~20 layers): first-step loss / logits / gradients
+rel 2e-5 of the tensor's scale; loss curve over 5 Adam steps rel 1e-4 (Adam divides by sqrt(v), which
+amplifies rounding noise of near-zero gradients).
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import quantized_cnn_amd.adp_qtz_fan as fan
+    import quantized_cnn_amd.adp_qtz_fix as fix
+    import quantized_cnn_amd.adp_qtz_hint as hint
+    from quantized_cnn_amd.train import TrainStep
+
+
+def cfg(mode="train"):
+    return argparse.Namespace(mode=mode, prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,
+                              prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+
+
+def fill_model_from_numpy(model, seed, keep_q):
+    """Must mirror tests/golden/make_golden.py:fill_model_from_numpy."""
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            n = p.numel()
+            if name.endswith("p_c"):
+                a = rs.random_sample(n)
+            elif name.endswith("q_level"):
+                a = rs.uniform(-0.2, 0.2, n)
+                if keep_q:
+                    continue
+            elif "bn" in name and name.endswith("weight"):
+                a = 1.0 + 0.1 * rs.standard_normal(n)
+            else:
+                a = 0.1 * rs.standard_normal(n)
+            p.copy_(torch.from_numpy(a.astype(np.float32)).reshape(p.shape))
+
+
+def build(variant, g, mode="train"):
+    mod = {"fan": fan, "fix": fix, "hint": hint}[variant]
+    c = cfg(mode)
+    mod.beta = 1
+    if variant == "fan":
+        model = mod.ResNet(c, 3)
+    else:
+        model = mod.ResNet(c, [float(v) for v in g[variant + "_s"]], torch.from_numpy(g[variant + "_v"]))
+    fill_model_from_numpy(model, int(g["seed_model"]), variant != "fan")
+    return mod, c, model.cuda()
+
+
+def close(a, b, rel):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= rel * np.abs(b).max() + 1e-12
+
+
+@pytest.mark.parametrize("variant", ["fan", "fix", "hint"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_five_training_steps_match_reference(golden, variant, graph):
+    g = golden("train")
+    k = variant + "_"
+    mod, c, model = build(variant, g)
+    assert list(model.state_dict().keys()) == list(g[k + "keys"])
+    assert [n for n, _ in model.named_parameters()] == list(g[k + "param_names"])
+    model.train()
+    x, y = torch.from_numpy(g[k + "x"]).cuda(), torch.from_numpy(g[k + "y"]).cuda()
+    step = TrainStep(model, c, mod, use_graph=graph)
+    losses = []
+    for it in range(int(g["steps"])):
+        if it == 3:
+            mod.beta = 2
+        if it == 0 and not graph:
+            # first step by hand to look at logits and gradients before the optimizers run
+            logits = model.forward(x)
+            reg = mod.model_loss(c, mod.beta, model)
+            loss = step.criterion(logits, y) + reg
+            loss.backward()
+            named = dict(model.named_parameters())
+            assert close(logits.detach().cpu().numpy(), g[k + "logits0"], 2e-5)
+            assert abs(reg.item() - g[k + "reg"][0]) <= 1e-5 * g[k + "reg"][0]
+            assert close(named["conv0.weight"].grad.cpu().numpy(), g[k + "g0_conv0"], 5e-5)
+            assert close(named["linear.bias"].grad.cpu().numpy(), g[k + "g0_bias"], 2e-5)
+            assert close(named["bn0.weight"].grad.cpu().numpy(), g[k + "g0_bn0_w"], 5e-5)
+            for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
+                assert close(named[n + ".p_c"].grad.reshape(-1)[:4096].cpu().numpy(), g[k + "dp0_head_" + n], 5e-5), n
+                if variant == "fix":
+                    assert named[n + ".q_level"].grad is None and g[k + "dq0_" + n].size == 0
+                else:
+                    assert close(named[n + ".q_level"].grad.cpu().numpy(), g[k + "dq0_" + n], 5e-5), n
+            for o in step.opts:
+                o.step()
+            for o in step.opts:
+                o.zero_grad()
+            losses.append(loss.item())
+            continue
+        losses.append(float(step(x, y)))
+    ref = g[k + "loss"]
+    assert abs(losses[0] - ref[0]) <= 2e-5 * ref[0], (losses, ref)
+    assert np.abs(np.array(losses) - ref).max() <= 1e-4 * ref.max(), (losses, ref)
+    named = dict(model.named_parameters())
+    for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
+        # five Adam steps of lr 1e-2 / 1e-3 move parameters by <= 5e-2 / 5e-3; sign flips of noise-level
+        # gradients can shift single coordinates by a step: compare at that resolution
+        assert close(named[n + ".p_c"].detach().reshape(-1)[:4096].cpu().numpy(), g[k + "p_final_head_" + n], 2e-2), n
+        assert close(named[n + ".q_level"].detach().cpu().numpy(), g[k + "q_final_" + n], 2e-2), n
+    sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
+    assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+
+
+def test_hard_mode_forward_uses_codes(golden):
+    """mode='test': weights are q_level[argmax] (adp_qtz_fan_test.py:304-305); checked against the
+    soft model's own oracle-verified pieces: hard logits == logits of a model whose W is replaced."""
+    from oracle import oracle as O
+    g = golden("train")
+    mod, c, model = build("fan", g, mode="test")
+    model.eval()
+    x = torch.from_numpy(g["fan_x"]).cuda()
+    with torch.no_grad():
+        logits = model.forward(x)
+    assert logits.shape == (x.shape[0], 10) and torch.isfinite(logits).all()
+    # layer-level check: conv of decoded codes
+    conv = model.layer2[0].conv1
+    r = O.synth_fwd(conv.p_c.detach().cpu().numpy(), conv.q_level.detach().cpu().numpy(), 1.0)
+    xin = torch.randn(2, 16, 32, 32, device="cuda")
+    with torch.no_grad():
+        y = conv(xin)
+    y_ref = O.conv_fwd(xin.cpu().numpy(), r["W_hard"], 2, 1)
+    assert np.abs(y.cpu().numpy() - y_ref).max() <= 2e-5 * np.abs(y_ref).max()
+
+
+def test_module_api_details():
+    c = cfg()
+    fan.beta = 1
+    conv = fan.MyConv2d(c, 4, 8, 3, 1, 1).cuda()
+    x = torch.randn(2, 4, 6, 6, device="cuda")
+    y1 = conv(x)
+    fan.beta = 4  # module-global sharpening factor is read at call time
+    y4 = conv(x)
+    assert not torch.equal(y1, y4)
+    conv.beta = 1  # explicit attribute wins
+    assert torch.equal(conv(x), y1)
+    fan.beta = 1
+    with pytest.raises(RuntimeError):
+        fan.MyConv2d(c, 4, 8, 3, 1, 1)(torch.randn(2, 4, 6, 6))  # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        fan.MyConv2d(c, 4, 8, 5, 1, 2).cuda()(x)
+    lin = fan.MyLinear(c, 64, 10).cuda()
+    assert lin.p_c.shape == (64, 10, 32) and lin(torch.randn(3, 64, device="cuda")).shape == (3, 10)
