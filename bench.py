@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the quantized-training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one optimisation step of the quantized ResNet-20 (adp_qtz_fan flavour, 32 learned
+levels) on a synthetic CIFAR-10 shaped batch of 128 images per GPU: one synthesis launch for the 19
+quantized layers, forward, CrossEntropy + model_loss, backward (MFMA conv dgrad/wgrad + one synthesis
+gradient launch), three Adam updates.  Inputs are resident in HBM before the timed region.  Prints
+one JSON line (rank 0).  Extra objects on that line:
+  roofline      the quantize kernel (weight-synthesis forward) on the standalone sweep tensor
+                (250 M primary coefficients, L=32): algorithmic bytes (132 B per weight row) / average
+                launch duration measured here with HIP events on the launch stream; peak = 8 TB/s
+  roofline_more the same for the synthesis gradient kernel (260 B/row) and, MFMA-bound, for the conv
+                forward / dgrad / wgrad kernels of the five ResNet-20 layer shapes (fp32 matrix peak)
+  cpu_baseline  the CPU port of the same training step (oracle/torch_port.py) timed on the host cores
+                for a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (spec)
+FP32_MATRIX_PEAK_TF = 157.3  # v_mfma_f32_* dense peak (spec)
+BATCH = 128
+
+
+def cfg():
+    return argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4,
+                              liar=True, prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+
+
+def event_time(fn, iters, warm=3):
+    """Average duration of fn() in seconds, HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / iters
+
+
+def kernel_rooflines(quick):
+    import quantized_cnn_amd.ops as ops
+    dev = "cuda"
+    L = 32
+    rows = (250_000_000 if not quick else 25_000_000) // L
+    g = torch.Generator(device=dev).manual_seed(0)
+    p = torch.rand(rows, L, device=dev, generator=g)
+    q = torch.tensor([-(2.0 ** -k) for k in range(2, 18)][::1] + [2.0 ** -k for k in range(17, 1, -1)], device=dev)
+    g.manual_seed(1)
+    dW = torch.randn(rows, device=dev, generator=g)
+    W = [torch.empty(rows, device=dev)]
+    dp = [torch.empty_like(p)]
+    t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20)
+    t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 10)
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("synth_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+    a1 = rows * (4 * L + 4) / t1 / 1e9
+    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8,true,false>", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
+    a2 = rows * (8 * L + 4) / t2 / 1e9
+    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8,true>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(a2 / HBM_PEAK_GBS, 4), "bytes_per_row": 8 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t2 * 1e3, 4)}]
+    del p, dW, W, dp
+    torch.cuda.empty_cache()
+    for (cin, cout, s, H) in [(16, 16, 1, 32), (16, 32, 2, 32), (32, 32, 1, 16), (32, 64, 2, 16), (64, 64, 1, 8)]:
+        x = torch.randn(BATCH, cin, H, H, device=dev)
+        Wc = torch.randn(cout, cin, 3, 3, device=dev) * 0.1
+        y = ops.conv_forward(x, Wc, s)
+        dy = torch.randn_like(y)
+        fl = 2.0 * BATCH * cout * cin * 9 * y.shape[2] * y.shape[3]
+        # launch-bound kernels: time a graph of 20 back-to-back launches so host launch latency is excluded
+        for name, fn in (("conv_fwd", lambda: ops.conv_forward(x, Wc, s)), ("conv_dgrad", lambda: ops.conv_dgrad(dy, Wc, x.shape, s)),
+                         ("conv_wgrad", lambda: ops.conv_wgrad(x, dy, s))):
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                fn()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(20):
+                        fn()
+            torch.cuda.current_stream().wait_stream(st)
+            t = event_time(gr.replay, 5, 2) / 20
+            more.append({"bound": "mfma", "kernel": "%s %d->%d s%d %dx%d N=%d" % (name, cin, cout, s, H, H, BATCH),
+                         "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+    return roof, more
+
+
+def cpu_baseline(quick):
+    """CPU port of the same step (oracle/torch_port.py, pinned to the reference by tests) on the host."""
+    from oracle import torch_port as TP
+    nthreads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(nthreads)
+    torch.manual_seed(0)
+    out = {}
+    for impl, steps in (("conv2d", 3 if not quick else 1), ("taps", 2 if not quick else 1)):
+        model = TP.PortModel("fan", 32, conv_impl=impl)
+        model.train()
+        opts = TP.optimizers(model)
+        x, y = torch.randn(BATCH, 3, 32, 32), torch.randint(0, 10, (BATCH,))
+        TP.train_step(model, opts, x, y)  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            TP.train_step(model, opts, x, y)
+        out[impl] = BATCH * steps / (time.perf_counter() - t0)
+    return {"value": round(out["conv2d"], 1), "unit": "img/s", "cores": nthreads, "kind": "port",
+            "sample": "3 steps of the same workload (batch 128) after 1 warm-up step, torch CPU fp32, F.conv2d formulation",
+            "value_nine_tap_formulation": round(out["taps"], 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--quick", action="store_true", help="smaller roofline tensor and CPU sample (development)")
+    ap.add_argument("--skip-extras", action="store_true", help="skip roofline and cpu_baseline measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import quantized_cnn_amd.adp_qtz_fan as fan
+    from quantized_cnn_amd.train import DataParallel, FusedTrainStep
+
+    c = cfg()
+    fan.beta = 1
+    torch.manual_seed(0)
+    model = fan.ResNet(c, 3).cuda()
+    model.train()
+    dp = DataParallel(model) if world > 1 else None
+    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
+    y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
+    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph)
+
+    for _ in range(args.warmup):
+        step(x, y)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(x, y)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    loss = float(step.loss)
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        out = {
+            "metric": "train img/s (quantized ResNet-20, synthetic CIFAR-10) + quantize-kernel HBM GB/s vs peak",
+            "value": round(world * BATCH * args.steps / elapsed, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: quantized ResNet-20 (adp_qtz_fan: 19 layers x 32 learned levels, soft "
+                                   "assignment) on synthetic CIFAR-10 32x32, full step fwd+CE+model_loss+bwd+3xAdam",
+                       "global_batch": world * BATCH, "per_gpu_batch": BATCH, "parallelism": "dp%d" % world,
+                       "hip_graphs": not args.no_graph},
+            "final_loss": round(loss, 5),
+        }
+        if not args.skip_extras:
+            roof, more = kernel_rooflines(args.quick)
+            out["roofline"] = roof
+            out["roofline_more"] = more
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(args.quick)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

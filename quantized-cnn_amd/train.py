@@ -168,3 +168,145 @@ def beta_schedule(config, epoch, beta, opts):
         for o in opts:
             o.param_groups[0]["lr"] /= 5
     return beta
+
+
+class FusedTrainStep:
+    """Same arithmetic as TrainStep, arranged for HIP graphs and data parallelism:
+
+        graph A : zero flat grads; ONE synthesis launch (W of all layers + sum W^2);
+                  forward; CE + l2_reg * sum(dense "weight"^2); backward with the synthesised W as
+                  leaves -> d loss/d W of every quantized layer lands in one flat buffer, dense
+                  gradients accumulate into views of the same buffer
+        comm    : one all-reduce of that buffer (only when world_size > 1; never captured)
+        graph B : ONE synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq); 3x Adam
+
+    Both graphs are captured once per (input shape, beta, learning rates) and replayed; with
+    use_graph=False the same two phases run eagerly.
+    """
+
+    def __init__(self, model, config, module, dp=None, use_graph=True):
+        self.model, self.config, self.module, self.dp = model, config, module, dp
+        self.use_graph = use_graph
+        self.criterion = nn.CrossEntropyLoss()
+        self.opts = make_optimizers(model, config, capturable=use_graph)
+        self.qlayers = model.quant_layers()
+        dev = next(model.parameters()).device
+        named = list(model.named_parameters())
+        self.dense = [p for n, p in named if "p_c" not in n and "q_level" not in n and p.requires_grad]
+        self.dense_reg = [p for n, p in named if "weight" in n and "p_c" not in n and "q_level" not in n]
+        self.ps = [l.p_c for l in self.qlayers]
+        self.qs = [l.q_level for l in self.qlayers]
+        self.sizes = [p.numel() // p.shape[-1] for p in self.ps]
+        nW = sum(self.sizes)
+        nD = sum(p.numel() for p in self.dense)
+        self.W_flat = torch.empty(nW, dtype=torch.float32, device=dev)
+        self.g_flat = torch.zeros(nW + nD, dtype=torch.float32, device=dev)  # [dW of all layers | dense grads]
+        self.Ws, self.slots, off = [], [], 0
+        for p, n in zip(self.ps, self.sizes):
+            self.Ws.append(self.W_flat[off:off + n].view(p.shape[:-1]))
+            self.slots.append(self.g_flat[off:off + n].view(p.shape[:-1]))
+            off += n
+        for p in self.dense:
+            p.grad = self.g_flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.dp_out = [torch.zeros_like(p) for p in self.ps]
+        self.dss = torch.full((len(self.ps),), float(config.l2_reg), dtype=torch.float32, device=dev)
+        self._graphs = None
+        self._key = None
+        self.loss = self.reg = self.logits = None
+
+    # ---- the two phases ---------------------------------------------------------------------
+    def _phase_a(self, x, y):
+        from . import ops
+        beta = float(self.module.beta)
+        self.g_flat.zero_()
+        out = ops.synth_forward([p.detach() for p in self.ps], [q.detach() for q in self.qs], beta, soft=True, sumsq=True,
+                                out_W=self.Ws)
+        leaves = []
+        for l, W, slot in zip(self.qlayers, self.Ws, self.slots):
+            w = W.detach().requires_grad_(True)
+            leaves.append(w)
+            l._shared = (w, slot)
+        self.model._synth_cache = None
+        logits = self._forward_body(x)
+        dense_sq = torch.cat([d.reshape(-1) for d in self.dense_reg]).pow(2).sum()
+        ce = self.criterion(logits, y)
+        (ce + self.config.l2_reg * dense_sq).backward()
+        for w in leaves:
+            w.grad = None
+        self.reg = (self.config.l2_reg * (dense_sq + out["sumsq"].sum())).detach()
+        self.loss = ce.detach() + self.reg
+        self.logits = logits.detach()
+
+    def _forward_body(self, x):
+        m = self.model
+        out = torch.relu(m.bn0(m.conv0(x)))
+        out = m.layer3(m.layer2(m.layer1(out)))
+        out = m.ap(torch.relu(m.bnlast(out)))
+        return m.linear(out.view(out.size(0), -1))
+
+    def _phase_b(self):
+        from . import ops
+        need_dq = [q.requires_grad for q in self.qs]
+        _, dq = ops.synth_backward([p.detach() for p in self.ps], [q.detach() for q in self.qs], float(self.module.beta),
+                                   self.slots, 0.0, need_dq=need_dq, out_dp=self.dp_out, dsumsq=self.dss)
+        for p, g in zip(self.ps, self.dp_out):
+            p.grad = g
+        for q, g in zip(self.qs, dq):
+            if g is not None:
+                if q.grad is None:
+                    q.grad = g
+                else:
+                    q.grad.copy_(g)
+        for o in self.opts:
+            o.step()
+
+    def _comm(self):
+        if self.dp is not None and self.dp.world > 1:
+            self.dp.reduce_flat(self.g_flat)
+
+    # ---- driver ------------------------------------------------------------------------------
+    def __call__(self, x, y):
+        if not self.use_graph:
+            self._phase_a(x, y)
+            self._comm()
+            self._phase_b()
+            return self.loss
+        key = (tuple(x.shape), float(self.module.beta), tuple(g["lr"] for o in self.opts for g in o.param_groups))
+        if self._graphs is None or key != self._key:
+            self._capture(x, y)
+            self._key = key
+        self._sx.copy_(x)
+        self._sy.copy_(y)
+        self._graphs[0].replay()
+        self._comm()
+        self._graphs[1].replay()
+        return self.loss
+
+    def _capture(self, x, y):
+        self._sx, self._sy = x.clone(), y.clone()
+        for o in self.opts:  # Adam creates its state lazily: create it here so that capture does not
+            for group in o.param_groups:
+                for p in group["params"]:
+                    if p.requires_grad and len(o.state[p]) == 0:
+                        o.state[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                        o.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        o.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        for q in self.qs:
+            if q.requires_grad and q.grad is None:
+                q.grad = torch.zeros_like(q)
+        for p, g in zip(self.ps, self.dp_out):
+            p.grad = g
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(ga, stream=s):
+                self._phase_a(self._sx, self._sy)
+            with torch.cuda.graph(gb, stream=s, pool=ga.pool()):
+                self._phase_b()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graphs = (ga, gb)
+        # capture does not execute: parameters are untouched until the first replay

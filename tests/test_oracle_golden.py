@@ -159,3 +159,51 @@ def test_expf_accuracy():
     ref = np.exp(x.astype(np.float64))
     assert np.max(np.abs(got - ref) / ref) < 1.3e-7
     assert np.isnan(O.expf(np.float32(np.nan)))
+
+
+def _fill_from_numpy(model, seed, keep_q):
+    """Mirrors tests/golden/make_golden.py:fill_model_from_numpy."""
+    import torch
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            n = p.numel()
+            if name.endswith("p_c"):
+                a = rs.random_sample(n)
+            elif name.endswith("q_level"):
+                a = rs.uniform(-0.2, 0.2, n)
+                if keep_q:
+                    continue
+            elif "bn" in name and name.endswith("weight"):
+                a = 1.0 + 0.1 * rs.standard_normal(n)
+            else:
+                a = 0.1 * rs.standard_normal(n)
+            p.copy_(torch.from_numpy(a.astype(np.float32)).reshape(p.shape))
+
+
+@pytest.mark.parametrize("variant,impl", [("fan", "conv2d"), ("fan", "taps"), ("fix", "conv2d"), ("hint", "conv2d")])
+def test_torch_port_training_curve_matches_reference(golden, variant, impl):
+    """The whole-step CPU port (used as cpu_baseline and as the model-level oracle) against five
+    optimisation steps of the reference's own classes."""
+    import torch
+    from oracle import torch_port as TP
+    torch.set_num_threads(8)
+    g = golden("train")
+    k = variant + "_"
+    s = [float(v) for v in g[k + "s"]]
+    model = TP.PortModel(variant, 32, s, torch.from_numpy(g[k + "v"]), conv_impl=impl)
+    assert [n for n, _ in model.named_parameters()] == list(g[k + "param_names"])
+    _fill_from_numpy(model, int(g["seed_model"]), variant != "fan")
+    model.train()
+    x, y = torch.from_numpy(g[k + "x"]), torch.from_numpy(g[k + "y"])
+    opts = TP.optimizers(model)
+    losses = []
+    for it in range(int(g["steps"])):
+        if it == 3:
+            model.beta = 2
+        loss, reg, logits = TP.train_step(model, opts, x, y)
+        losses.append(loss)
+        if it == 0:
+            assert np.abs(logits.numpy() - g[k + "logits0"]).max() <= 2e-5 * np.abs(g[k + "logits0"]).max()
+            assert abs(reg - g[k + "reg"][0]) <= 1e-5 * g[k + "reg"][0]
+    assert np.abs(np.array(losses) - g[k + "loss"]).max() <= 1e-4 * g[k + "loss"].max()
