@@ -272,11 +272,19 @@ class QResNet(nn.Module):
         self._synth_cache = None  # one use per forward
         return c["sumsq"]
 
+    def stem(self, x):
+        """conv0 is a full-precision nn.Conv2d in the reference (adp_qtz_fan.py:699); its weight stays
+        an ordinary dense parameter, the arithmetic runs on the same MFMA convolution kernels."""
+        c0 = self.conv0
+        if c0.kernel_size == (3, 3) and c0.padding == (1, 1) and c0.stride in ((1, 1), (2, 2)) and c0.bias is None:
+            return _Conv3x3.apply(x, c0.weight, c0.stride[0], None)
+        return c0(x)
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._synthesize_all()
-        out = F.relu(self.bn0(self.conv0(x)))
+        out = F.relu(self.bn0(self.stem(x)))
         out = self.layer1(out)
         out = self.layer2(out)
         out = self.layer3(out)

@@ -240,7 +240,7 @@ class FusedTrainStep:
 
     def _forward_body(self, x):
         m = self.model
-        out = torch.relu(m.bn0(m.conv0(x)))
+        out = torch.relu(m.bn0(m.stem(x)))
         out = m.layer3(m.layer2(m.layer1(out)))
         out = m.ap(torch.relu(m.bnlast(out)))
         return m.linear(out.view(out.size(0), -1))
@@ -302,6 +302,15 @@ class FusedTrainStep:
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
+            # one eager pass of phase A so that libraries used by the stock ops (BatchNorm, pooling)
+            # finish their lazy initialisation outside the capture; it changes no parameter, and the
+            # BatchNorm running statistics it touches are put back
+            bufs = [b for b in self.model.buffers()]
+            saved = [b.clone() for b in bufs]
+            self._phase_a(self._sx, self._sy)
+            for b, v in zip(bufs, saved):
+                b.copy_(v)
+            torch.cuda.synchronize()
             with torch.cuda.graph(ga, stream=s):
                 self._phase_a(self._sx, self._sy)
             with torch.cuda.graph(gb, stream=s, pool=ga.pool()):
