@@ -330,14 +330,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     }
 }
 
-// dW[i] = sum over slabs in ascending order
+// dW[i] = sum over the workgroup slabs.  A workgroup owns 32 consecutive elements; 8 thread rows
+// each add every 8th slab in ascending order, then the 8 running sums are added in order 0..7.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float sh[8][33];
+    const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
     float s = 0.0f;
-    for (int b = 0; b < nslab; ++b) s += part[(long long)b * n + i];
-    dW[i] = s;
+    if (i < n)
+        for (int b = sg; b < nslab; b += 8) s += part[(long long)b * n + i];
+    sh[sg][c] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        float t = sh[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][c];
+        dW[i] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------- host side
@@ -506,7 +516,7 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nW = Cout * Cin * 9;
     if (N == 0) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 255) / 256), dim3(256), 0, st, nullptr, dW, nW, 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, nullptr, dW, nW, 0);
         return check_launch("aq_conv_wgrad");
     }
     AQ_REQUIRE(x && dy, -EFAULT, "aq_conv_wgrad: NULL pointer");
@@ -527,7 +537,7 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     else AQ_WG(1, 36);
 #undef AQ_WG
     if (int rc = check_launch("aq_conv_wgrad")) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 255) / 256), dim3(256), 0, st, a.part, dW, nW, (int)grid.x);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, a.part, dW, nW, (int)grid.x);
     return check_launch("aq_conv_wgrad(reduce)");
 }
 

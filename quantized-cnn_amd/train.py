@@ -48,6 +48,8 @@ class DataParallel:
         self.dist, self.group = dist, process_group
         self.world = dist.get_world_size(process_group)
         self.model = model
+        # gloo (tests, CPU rehearsals) moves device tensors through the host; RCCL works on them in place
+        self.host_staged = dist.get_backend(process_group) == "gloo"
         if sync_bn and self.world > 1:
             nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group)
         _, _, rest = split_parameters(model)
@@ -56,10 +58,21 @@ class DataParallel:
         # identical initial parameters on every rank
         if self.world > 1:
             for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, 0, group=process_group)
+                if self.host_staged and t.is_cuda:
+                    h = t.data.cpu()
+                    dist.broadcast(h, 0, group=process_group)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, 0, group=process_group)
 
     def reduce_flat(self, flat):
-        self.dist.all_reduce(flat, group=self.group)
+        """In-place mean over ranks of one flat gradient buffer (a single all-reduce)."""
+        if self.host_staged and flat.is_cuda:
+            h = flat.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            flat.copy_(h)
+        else:
+            self.dist.all_reduce(flat, group=self.group)
         flat.div_(self.world)
 
     def reduce_dense(self):
