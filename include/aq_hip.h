@@ -20,9 +20,14 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 1
+#define AQ_ABI_VERSION 2
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
+/* flags of aq_synth_fwd / aq_synth_bwd */
+#define AQ_FLAG_EXACT 1u      /* bit-reproducible arithmetic (polynomial exp): results equal the CPU
+                                 restatement of the same operation sequence bit for bit.  Without it exp
+                                 runs on the transcendental unit (faster; same results within ~1e-6).
+                                 Launches that emit codes (idx / W_hard) always use the exact sequence. */
 
 /* One quantized layer ("segment") of a multi-layer launch.  rows = number of weights of the layer
  * (Cout*Cin*k*k for MyConv2d.p_c, in*out for MyLinear.p_c), L = number of levels (innermost,
@@ -53,13 +58,13 @@ const char *aq_last_error(void);
  * requested).  Replaces MyConv2d.forward lines adp_qtz_fan.py:563-571 / MyLinear.forward
  * :634-643 and the per-layer re-synthesis inside model_loss :747-752.
  * workspace must hold aq_synth_workspace_bytes(segs, nseg, 0) bytes. */
-int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, void *workspace, size_t workspace_bytes,
-                 void *stream);
+int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void *workspace,
+                 size_t workspace_bytes, void *stream);
 
 /* Gradient of the synthesis: for every layer g = dW + wd*W (wd = 2*l2_reg*dLoss/dReg folds the
  * regulariser of adp_qtz_fan.py:737-754 in), then dp_c and dq as autograd derives them from
  * adp_qtz_fan.py:563-568.  workspace must hold aq_synth_workspace_bytes(segs, nseg, 1) bytes. */
-int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, void *workspace,
+int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace,
                  size_t workspace_bytes, void *stream);
 
 size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward);

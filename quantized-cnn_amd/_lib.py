@@ -10,8 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaq_hip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
+ABI_VERSION = 2
+FLAG_EXACT = 1
 MAX_LEVELS = 128
 
 EXPORTS = (
@@ -43,8 +44,8 @@ def lib():
         vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
         L.aq_abi_version.restype = i
         L.aq_last_error.restype = C.c_char_p
-        L.aq_synth_fwd.argtypes = [C.POINTER(AqSeg), i, f, vp, sz, vp]
-        L.aq_synth_bwd.argtypes = [C.POINTER(AqSeg), i, f, f, vp, sz, vp]
+        L.aq_synth_fwd.argtypes = [C.POINTER(AqSeg), i, f, C.c_uint, vp, sz, vp]
+        L.aq_synth_bwd.argtypes = [C.POINTER(AqSeg), i, f, f, C.c_uint, vp, sz, vp]
         L.aq_synth_workspace_bytes.argtypes = [C.POINTER(AqSeg), i, i]
         L.aq_synth_workspace_bytes.restype = sz
         conv_dims = [i] * 8

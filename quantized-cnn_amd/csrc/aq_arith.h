@@ -122,4 +122,10 @@ __device__ __forceinline__ float chain_dot(const float (&a)[4], const float (&b)
 }
 __device__ __forceinline__ float inv_norm(float ss) { return 1.0f / __builtin_sqrtf(ss); }
 
+// Fast arithmetic (default): exp(x) = 2^(x*log2 e) on the transcendental unit (v_exp_f32, about
+// 1 ulp, plus |x|*2^-24 from the scaled argument).  Not reproducible on a CPU, so results are
+// compared with the oracle within a tolerance; the EXACT kernels use expf_spec instead.
+constexpr float LOG2E = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+__device__ __forceinline__ float exp2_hw(float x2) { return __builtin_amdgcn_exp2f(x2); }
+
 } // namespace aq

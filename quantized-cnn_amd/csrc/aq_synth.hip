@@ -87,7 +87,9 @@ __device__ __forceinline__ int find_segment(const SegTab &tab)
     return si;
 }
 
-template <int G, bool VEC, bool HARD>
+// EXACT: the bit-reproducible operation sequence (polynomial exp); otherwise exp on the
+// transcendental unit.  HARD (codes) implies EXACT at the call site.
+template <int G, bool VEC, bool HARD, bool EXACT>
 __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
 {
     constexpr int RPP = 64 / G;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                 const float ss = group_sum<G>(chain_sq(v[u]));
                 my_ss = (j == ub + u) ? ss : my_ss;
             }
-            const float my_rn = inv_norm(my_ss);
+            // EXACT: 1/||p||; fast: beta*log2(e)/||p||, so that one multiply per element feeds v_exp_f32
+            const float my_rn = EXACT ? inv_norm(my_ss) : (beta * inv_norm(my_ss)) * LOG2E;
             float my_den = 1.0f, my_num = 0.0f;
             uint32_t my_bi = 0;
             static_for<8>([&](auto U) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                 float e[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float ex = expf_spec(beta * (v[u][k] * rn));
+                    const float ex = EXACT ? expf_spec(beta * (v[u][k] * rn)) : exp2_hw(v[u][k] * rn);
                     e[k] = (VEC || valid[k]) ? ex : 0.0f;
                 }
                 const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
     }
 }
 
-template <int G, bool VEC>
+template <int G, bool VEC, bool EXACT>
 __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd)
 {
     constexpr int RPP = 64 / G;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     pn[k] = v[u][k] * rn;
-                    const float ex = expf_spec(beta * pn[k]);
+                    const float ex = EXACT ? expf_spec(beta * pn[k]) : exp2_hw(pn[k] * (beta * LOG2E));
                     e[k] = (VEC || valid[k]) ? ex : 0.0f;
                 }
                 const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
@@ -291,14 +294,17 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     }
 }
 
-// Second stage of the cross-row sums: one workgroup per layer adds the layer's per-wavefront
-// partials.  Thread (ln, lvl) adds partials ln, ln+NL, ln+2NL, .. of column lvl in that order,
-// then the NL running sums of a column are combined by a halving tree in LDS.
+// Second stage of the cross-row sums: adds the per-wavefront partials of each layer in a fixed
+// order.  A workgroup of 1024 threads = NL thread rows x `width` columns (NL = 1024/width) owns a
+// chunk of 32*NL consecutive partial rows: thread row r adds rows r, r+NL, r+2NL, .. of the chunk
+// in that order, then the NL running sums of a column are combined by a halving tree in LDS.
+// Layers with more partials than one chunk are reduced level by level (chunk results become the
+// partials of the next level), so the order depends only on the number of rows.
 struct RedSeg {
     const float *part;
     float *out;
     long long n;
-    int width, outw;
+    int width, outw, blk0, pad;
 };
 struct RedTab {
     int nseg;
@@ -308,29 +314,42 @@ struct RedTab {
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const RedTab tab)
 {
     __shared__ float sh[1024];
-    const RedSeg sg = tab.s[blockIdx.x];
+    int si = 0;
+    for (int i = 1; i < tab.nseg; ++i)
+        if ((int)blockIdx.x >= tab.s[i].blk0) si = i;
+    const RedSeg sg = tab.s[si];
     const int tid = threadIdx.x;
     const int width = sg.width, nl = 1024 / width;
     const int lvl = tid % width, ln = tid / width;
+    const long long chunk = (long long)((int)blockIdx.x - sg.blk0);
+    const long long r0 = chunk * 32 * nl;
+    const long long r1 = r0 + 32 * nl < sg.n ? r0 + 32 * nl : sg.n;
     float a = 0.0f;
-    for (long long i = ln; i < sg.n; i += nl) a += sg.part[i * width + lvl];
+    for (long long i = r0 + ln; i < r1; i += nl) a += sg.part[i * width + lvl];
     sh[tid] = a;
     __syncthreads();
     for (int s = nl >> 1; s >= 1; s >>= 1) {
         if (ln < s) sh[tid] += sh[tid + s * width];
         __syncthreads();
     }
-    if (ln == 0 && lvl < sg.outw) sg.out[lvl] = sh[lvl];
+    // a single-chunk level writes the layer's result (outw columns); otherwise one row per chunk
+    const bool last = sg.n <= 32 * nl;
+    if (ln == 0 && lvl < (last ? sg.outw : width)) sg.out[(last ? 0 : chunk * width) + lvl] = sh[lvl];
 }
 
 // ------------------------------------------------------------------------------------ host side
 
 static inline int lanes_for(int L) { return L <= 32 ? 8 : (L <= 64 ? 16 : 32); }
 
+// Iterations (of 64 rows) per wavefront.  One: the kernels are bound by load latency, and more,
+// shorter-lived wavefronts overlap better than long ones (measured: 5.7 TB/s at 1, 4.7 TB/s at 16).
 static inline int choose_K(long long total_rows)
 {
-    long long k = total_rows / (256LL * 4096LL);
-    return (int)std::min<long long>(16, std::max<long long>(1, k));
+#ifdef AQ_EXPERIMENT
+    if (const char *e = getenv("AQ_SYNTH_K")) return atoi(e);
+#endif
+    (void)total_rows;
+    return 1;
 }
 
 static inline long long wave_tiles(long long rows, int K) { return (rows + (long long)K * ROWS_IT - 1) / ((long long)K * ROWS_IT); }
@@ -338,8 +357,12 @@ static inline long long wave_tiles(long long rows, int K) { return (rows + (long
 struct Plan {
     int K;
     size_t bytes;
-    size_t off[1 << 12];
+    size_t off[1 << 12];   // per-wavefront partials of segment i
+    size_t tmp[1 << 12];   // two ping-pong areas for the multi-level reduction of segment i
+    size_t tmp_half[1 << 12];
 };
+
+static inline long long red_chunks(long long n, int width) { const long long ch = 32LL * (1024 / width); return (n + ch - 1) / ch; }
 
 static int validate(const aq_seg *segs, int nseg, float beta, bool bwd)
 {
@@ -368,23 +391,30 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
         const bool need = bwd ? segs[i].dq != nullptr : segs[i].sumsq != nullptr;
         if (need && segs[i].rows > 0) {
             const size_t width = bwd ? 4 * lanes_for(segs[i].L) : 1;
-            size_t n = (size_t)wave_tiles(segs[i].rows, pl.K) * width * sizeof(float);
+            const long long nw = wave_tiles(segs[i].rows, pl.K);
+            size_t n = (size_t)nw * width * sizeof(float);
             off += (n + 255) & ~(size_t)255;
+            pl.tmp[i] = off;
+            pl.tmp_half[i] = (((size_t)red_chunks(nw, (int)width) * width * sizeof(float)) + 255) & ~(size_t)255;
+            off += 2 * pl.tmp_half[i];
         }
     }
     pl.bytes = off;
 }
 
 template <bool BWD>
-static void launch_class(int G, bool vec, bool hard, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
+static void launch_class(int G, bool vec, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
 {
-#define AQ_LAUNCH(GG, VV)                                                                                           \
-    if (BWD)                                                                                                        \
-        hipLaunchKernelGGL((synth_bwd_kernel<GG, VV>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);             \
-    else if (hard)                                                                                                  \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);           \
-    else                                                                                                            \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
+#define AQ_LAUNCH(GG, VV)                                                                                             \
+    if (BWD) {                                                                                                        \
+        if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, VV, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd); \
+        else hipLaunchKernelGGL((synth_bwd_kernel<GG, VV, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);   \
+    } else if (hard)                                                                                                  \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
+    else if (exact)                                                                                                   \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);      \
+    else                                                                                                              \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
     if (G == 8) { if (vec) { AQ_LAUNCH(8, true) } else { AQ_LAUNCH(8, false) } }
     else if (G == 16) { if (vec) { AQ_LAUNCH(16, true) } else { AQ_LAUNCH(16, false) } }
     else { if (vec) { AQ_LAUNCH(32, true) } else { AQ_LAUNCH(32, false) } }
@@ -392,8 +422,9 @@ static void launch_class(int G, bool vec, bool hard, const SegTab &tab, int nblo
 }
 
 template <bool BWD>
-static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspace, size_t workspace_bytes, hipStream_t st)
+static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
+    const bool exact = (flags & AQ_FLAG_EXACT) != 0;
     if (int rc = validate(segs, nseg, beta, BWD)) return rc;
     static thread_local Plan pl;
     make_plan(segs, nseg, BWD, pl);
@@ -410,7 +441,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspa
             int nblocks = 0;
             bool hard = false;
             auto flush = [&]() {
-                if (tab.nseg) launch_class<BWD>(G, vec != 0, hard, tab, nblocks, beta, wd, st);
+                if (tab.nseg) launch_class<BWD>(G, vec != 0, hard, exact, tab, nblocks, beta, wd, st);
                 tab.nseg = 0;
                 nblocks = 0;
                 hard = false;
@@ -436,26 +467,55 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspa
         }
     if (int rc = check_launch(BWD ? "aq_synth_bwd" : "aq_synth_fwd")) return rc;
 
-    // second stage: fixed-order sum of the per-wavefront partials of each layer
-    RedTab red;
-    red.nseg = 0;
-    auto flush_red = [&]() {
-        if (red.nseg) hipLaunchKernelGGL(reduce_partials_kernel, dim3(red.nseg), dim3(1024), 0, st, red);
-        red.nseg = 0;
-    };
+    // second stage: fixed-order sum of the per-wavefront partials of each layer, level by level
+    static thread_local long long cur_n[1 << 12];
+    static thread_local const float *cur_src[1 << 12];
+    bool more = false;
     for (int i = 0; i < nseg; ++i) {
         const aq_seg &s = segs[i];
         float *out = BWD ? s.dq : s.sumsq;
+        cur_n[i] = -1;
         if (!out) continue;
-        RedSeg &r = red.s[red.nseg];
-        r.part = reinterpret_cast<const float *>(static_cast<const char *>(workspace) + pl.off[i]);
-        r.out = out;
-        r.n = s.rows ? wave_tiles(s.rows, pl.K) : 0;
-        r.width = BWD ? 4 * lanes_for(s.L) : 1;
-        r.outw = BWD ? s.L : 1;
-        if (++red.nseg == MAX_SEGS) flush_red();
+        cur_n[i] = s.rows ? wave_tiles(s.rows, pl.K) : 0;
+        cur_src[i] = reinterpret_cast<const float *>(static_cast<const char *>(workspace) + pl.off[i]);
+        more = true;
     }
-    flush_red();
+    for (int level = 0; more; ++level) {
+        more = false;
+        RedTab red;
+        red.nseg = 0;
+        int nblocks = 0;
+        auto flush_red = [&]() {
+            if (red.nseg) hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblocks), dim3(1024), 0, st, red);
+            red.nseg = 0;
+            nblocks = 0;
+        };
+        for (int i = 0; i < nseg; ++i) {
+            if (cur_n[i] < 0) continue;
+            const aq_seg &s = segs[i];
+            const int width = BWD ? 4 * lanes_for(s.L) : 1;
+            const long long chunks = std::max<long long>(1, red_chunks(cur_n[i], width));
+            RedSeg &r = red.s[red.nseg];
+            r.part = cur_src[i];
+            r.n = cur_n[i];
+            r.width = width;
+            r.outw = BWD ? s.L : 1;
+            r.blk0 = nblocks;
+            if (chunks == 1) {
+                r.out = BWD ? s.dq : s.sumsq;
+                cur_n[i] = -1;
+            } else {
+                float *dst = reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.tmp[i] + (level & 1) * pl.tmp_half[i]);
+                r.out = dst;
+                cur_src[i] = dst;
+                cur_n[i] = chunks;
+                more = true;
+            }
+            nblocks += (int)chunks;
+            if (++red.nseg == MAX_SEGS) flush_red();
+        }
+        flush_red();
+    }
     return check_launch(BWD ? "aq_synth_bwd(reduce)" : "aq_synth_fwd(reduce)");
 }
 
@@ -463,14 +523,14 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, void *workspa
 
 extern "C" {
 
-int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, void *workspace, size_t workspace_bytes, void *stream)
+int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return aq::run<false>(segs, nseg, beta, 0.0f, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return aq::run<false>(segs, nseg, beta, 0.0f, flags, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, void *workspace, size_t workspace_bytes, void *stream)
+int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return aq::run<true>(segs, nseg, beta, wd, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return aq::run<true>(segs, nseg, beta, wd, flags, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward)

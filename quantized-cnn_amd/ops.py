@@ -9,6 +9,14 @@ import torch
 
 from . import _lib
 
+# Default arithmetic of the synthesis kernels: False = exp on the transcendental unit (fastest);
+# True = bit-reproducible operation sequence (equal to the CPU restatement bit for bit).
+EXACT_ARITHMETIC = False
+
+
+def _flags(exact):
+    return _lib.FLAG_EXACT if (EXACT_ARITHMETIC if exact is None else exact) else 0
+
 
 def _rows_L(p):
     L = p.shape[-1]
@@ -36,7 +44,7 @@ def _workspace(segs, n, backward, device):
     return ws, nbytes
 
 
-def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out_W=None):
+def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out_W=None, exact=None):
     """Weight synthesis of several layers in one launch.
 
     p_list[i]: (..., L_i) fp32, q_list[i]: (L_i,).  Returns a dict with (as requested)
@@ -44,6 +52,8 @@ def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out
       "idx"    list of uint8 codes, "W_hard" list of q[idx]      (adp_qtz_fan_test.py:304-305)
       "sumsq"  fp32 tensor [n]: sum of W^2 per layer             (adp_qtz_fan.py:752)
     out_W: optional list of preallocated fp32 tensors to receive W.
+    exact: True = bit-reproducible arithmetic, False = fast, None = module default EXACT_ARITHMETIC
+    (launches that emit codes are always exact).
     """
     n = len(p_list)
     segs = _seg_array(p_list, q_list)
@@ -67,11 +77,11 @@ def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out
         for i in range(n):
             segs[i].sumsq = base + 4 * i
     ws, nbytes = _workspace(segs, n, False, dev)
-    _lib.check(_lib.lib().aq_synth_fwd(segs, n, float(beta), ws.data_ptr(), nbytes, _lib.stream()))
+    _lib.check(_lib.lib().aq_synth_fwd(segs, n, float(beta), _flags(exact), ws.data_ptr(), nbytes, _lib.stream()))
     return out
 
 
-def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None, dsumsq=None):
+def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None, dsumsq=None, exact=None):
     """Gradient of the synthesis for several layers in one launch.
 
     dW_list[i]: upstream d loss/d W (shape p.shape[:-1]) or None; wd = 2*l2_reg*(d loss/d reg).
@@ -96,7 +106,7 @@ def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=N
         if dq[i] is not None:
             segs[i].dq = _lib.ptr(dq[i], name="dq[%d]" % i)
     ws, nbytes = _workspace(segs, n, True, dev)
-    _lib.check(_lib.lib().aq_synth_bwd(segs, n, float(beta), float(wd), ws.data_ptr(), nbytes, _lib.stream()))
+    _lib.check(_lib.lib().aq_synth_bwd(segs, n, float(beta), float(wd), _flags(exact), ws.data_ptr(), nbytes, _lib.stream()))
     return dp, dq
 
 

@@ -36,10 +36,10 @@ def test_argument_errors_are_reported_without_a_gpu():
     lib = L.lib()
     segs = (L.AqSeg * 1)()
     segs[0].rows, segs[0].L = 4, 500
-    assert lib.aq_synth_fwd(segs, 1, 1.0, None, 0, None) < 0
+    assert lib.aq_synth_fwd(segs, 1, 1.0, 0, None, 0, None) < 0
     assert b"L=500" in lib.aq_last_error()
     segs[0].L = 32
-    assert lib.aq_synth_fwd(segs, 1, 1000.0, None, 0, None) < 0
+    assert lib.aq_synth_fwd(segs, 1, 1000.0, 0, None, 0, None) < 0
     assert b"beta" in lib.aq_last_error()
     assert lib.aq_conv_fwd(None, None, None, 1, 3, 8, 8, 4, 5, 1, 2, None) < 0
     assert b"3x3" in lib.aq_last_error()
