@@ -42,11 +42,17 @@ struct SegTab {
     SegDev s[MAX_SEGS];
 };
 
-template <int G, bool VEC>
+// MEM: 0 = rows only 4-byte aligned (L != 4G or unaligned base), 1 = 16-byte vector access,
+// 2 = 16-byte vector access with the nontemporal (streaming) cache policy, chosen by the host for
+// tensors larger than the last-level cache: +7 % (forward) / +10 % (backward) at 1 GB.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int G, int MEM>
 __device__ __forceinline__ void load_elems(const float *__restrict__ p, long long r, int L, int j, float (&v)[4])
 {
-    if constexpr (VEC) {
-        const float4 t = reinterpret_cast<const float4 *>(p)[r * G + j];
+    if constexpr (MEM != 0) {
+        const f4 *src = reinterpret_cast<const f4 *>(p) + (r * G + j);
+        const f4 t = (MEM == 2) ? __builtin_nontemporal_load(src) : *src;
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
         const float *a = p + r * (long long)L + 4 * j;
@@ -61,11 +67,14 @@ __device__ __forceinline__ void load_elems(const float *__restrict__ p, long lon
     }
 }
 
-template <int G, bool VEC>
+template <int G, int MEM>
 __device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, int L, int j, const float (&v)[4])
 {
-    if constexpr (VEC) {
-        reinterpret_cast<float4 *>(p)[r * G + j] = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (MEM != 0) {
+        f4 *dst = reinterpret_cast<f4 *>(p) + (r * G + j);
+        const f4 t = {v[0], v[1], v[2], v[3]};
+        if (MEM == 2) __builtin_nontemporal_store(t, dst);
+        else *dst = t;
     } else {
         float *a = p + r * (long long)L + 4 * j;
         if (4 * j + 3 < L) {
@@ -89,7 +98,7 @@ __device__ __forceinline__ int find_segment(const SegTab &tab)
 
 // EXACT: the bit-reproducible operation sequence (polynomial exp); otherwise exp on the
 // transcendental unit.  HARD (codes) implies EXACT at the call site.
-template <int G, bool VEC, bool HARD, bool EXACT>
+template <int G, int MEM, bool HARD, bool EXACT>
 __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
 {
     constexpr int RPP = 64 / G;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long long r = row0 + (ub + u) * RPP + gq;
-                load_elems<G, VEC>(p, r < rows ? r : rows - 1, L, j, v[u]);
+                load_elems<G, MEM>(p, r < rows ? r : rows - 1, L, j, v[u]);
             }
             // squared norms of the 8 rows; lane j == ub+u keeps row u's and inverts it once
             float my_ss = 1.0f;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float ex = EXACT ? expf_spec(beta * (v[u][k] * rn)) : exp2_hw(v[u][k] * rn);
-                    e[k] = (VEC || valid[k]) ? ex : 0.0f;
+                    e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
                 }
                 const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
                 const float num = group_sum<G>(chain_dot(e, q4));
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
     }
 }
 
-template <int G, bool VEC, bool EXACT>
+template <int G, int MEM, bool EXACT>
 __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd)
 {
     constexpr int RPP = 64 / G;
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
             for (int u = 0; u < 8; ++u) {
                 const long long r = row0 + (ub + u) * RPP + gq;
                 const long long rc = r < rows ? r : rows - 1;
-                load_elems<G, VEC>(p, rc, L, j, v[u]);
+                load_elems<G, MEM>(p, rc, L, j, v[u]);
                 gw[u] = dW ? dW[rc] : 0.0f;
             }
             float my_ss = 1.0f;
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                 for (int k = 0; k < 4; ++k) {
                     pn[k] = v[u][k] * rn;
                     const float ex = EXACT ? expf_spec(beta * pn[k]) : exp2_hw(pn[k] * (beta * LOG2E));
-                    e[k] = (VEC || valid[k]) ? ex : 0.0f;
+                    e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
                 }
                 const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
                 const float num = group_sum<G>(chain_dot(e, q4));
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
                 if (r < rows) {
-                    store_elems<G, VEC>(dp, r, L, j, o);
+                    store_elems<G, MEM>(dp, r, L, j, o);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
                 }
@@ -403,21 +412,26 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
 }
 
 template <bool BWD>
-static void launch_class(int G, bool vec, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
+static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
 {
-#define AQ_LAUNCH(GG, VV)                                                                                             \
+#define AQ_LAUNCH(GG, MM)                                                                                             \
     if (BWD) {                                                                                                        \
-        if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, VV, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd); \
-        else hipLaunchKernelGGL((synth_bwd_kernel<GG, VV, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);   \
+        if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd); \
+        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);   \
     } else if (hard)                                                                                                  \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
     else if (exact)                                                                                                   \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);      \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);      \
     else                                                                                                              \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, VV, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
-    if (G == 8) { if (vec) { AQ_LAUNCH(8, true) } else { AQ_LAUNCH(8, false) } }
-    else if (G == 16) { if (vec) { AQ_LAUNCH(16, true) } else { AQ_LAUNCH(16, false) } }
-    else { if (vec) { AQ_LAUNCH(32, true) } else { AQ_LAUNCH(32, false) } }
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
+#define AQ_LAUNCH_G(GG)                      \
+    if (mem == 2) { AQ_LAUNCH(GG, 2) }       \
+    else if (mem == 1) { AQ_LAUNCH(GG, 1) }  \
+    else { AQ_LAUNCH(GG, 0) }
+    if (G == 8) { AQ_LAUNCH_G(8) }
+    else if (G == 16) { AQ_LAUNCH_G(16) }
+    else { AQ_LAUNCH_G(32) }
+#undef AQ_LAUNCH_G
 #undef AQ_LAUNCH
 }
 
@@ -432,7 +446,12 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                pl.bytes, workspace_bytes);
     AQ_REQUIRE(((uintptr_t)workspace & 15) == 0, -EINVAL, "workspace must be 16-byte aligned");
 
-    // main launches: one per (lanes-per-row, vector-aligned) class, at most MAX_SEGS segments each
+    // streaming cache policy when the tensors cannot stay in the 256 MiB last-level cache anyway
+    long long total_bytes = 0;
+    for (int i = 0; i < nseg; ++i) total_bytes += segs[i].rows * (long long)segs[i].L * 4;
+    const bool stream_policy = total_bytes > (128LL << 20);
+
+    // main launches: one per (lanes-per-row, memory access) class, at most MAX_SEGS segments each
     for (int G = 8; G <= 32; G <<= 1)
         for (int vec = 0; vec < 2; ++vec) {
             SegTab tab;
@@ -441,7 +460,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             int nblocks = 0;
             bool hard = false;
             auto flush = [&]() {
-                if (tab.nseg) launch_class<BWD>(G, vec != 0, hard, exact, tab, nblocks, beta, wd, st);
+                if (tab.nseg) launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, st);
                 tab.nseg = 0;
                 nblocks = 0;
                 hard = false;
