@@ -81,7 +81,7 @@ def synth_forward(p_list, q_list, beta, soft=True, codes=False, sumsq=False, out
     return out
 
 
-def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None, dsumsq=None, exact=None):
+def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=None, dsumsq=None, exact=None, out_dq=None):
     """Gradient of the synthesis for several layers in one launch.
 
     dW_list[i]: upstream d loss/d W (shape p.shape[:-1]) or None; wd = 2*l2_reg*(d loss/d reg).
@@ -94,7 +94,10 @@ def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=N
     dev = p_list[0].device
     need_dq = [True] * n if need_dq is None else list(need_dq)
     dp = out_dp if out_dp is not None else [torch.empty_like(p) for p in p_list]
-    dq = [torch.empty_like(q) if need else None for q, need in zip(q_list, need_dq)]
+    if out_dq is not None:
+        dq = [o if need else None for o, need in zip(out_dq, need_dq)]
+    else:
+        dq = [torch.empty_like(q) if need else None for q, need in zip(q_list, need_dq)]
     for i in range(n):
         if dW_list[i] is not None:
             if dW_list[i].numel() != segs[i].rows:

@@ -1,0 +1,16 @@
+"""Development aid for counter collection: a few launches of the synthesis forward / backward
+kernels on the sweep tensor and nothing else."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import quantized_cnn_amd.ops as ops
+L = 32
+rows = 250_000_000 // L
+p = torch.rand(rows, L, device="cuda"); q = torch.linspace(-0.25, 0.25, L, device="cuda")
+dW = torch.randn(rows, device="cuda"); W = [torch.empty(rows, device="cuda")]; dp = [torch.empty_like(p)]
+for _ in range(5):
+    ops.synth_forward([p], [q], 4.0, out_W=W)
+for _ in range(5):
+    ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp)
+torch.cuda.synchronize()
+print("rows", rows, "alg bytes fwd", rows * 132, "bwd", rows * 260)
