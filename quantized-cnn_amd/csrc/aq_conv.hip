@@ -48,7 +48,77 @@ struct ConvArgs {
     int pitch, rows_in, plane;
     int Kpad;
     int vecA;            // rows of A are 16-byte aligned and K % 4 == 0
+    int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
 };
+
+// Fill the LDS image xs[nch][plane] of one input tile: plane = rows_in x pitch elements starting at
+// (r0, c0) in (dilated) input coordinates, zero outside the tensor.  Lanes own plane elements
+// (lane, lane+64, ..), wavefronts own channels (wave, wave+4, ..).  The geometry of a lane's
+// elements (row/column, bounds, global offset) is worked out once and reused for every channel, and
+// the loads of four channels are all issued before the first LDS store, so one wavefront keeps up to
+// 4*ceil(plane/64) loads in flight (the fill is latency-bound, not bandwidth-bound).
+constexpr int STAGE_MAXJ = 10;  // plane <= 640 elements
+
+__device__ __forceinline__ void stage_image(float *__restrict__ xs, const float *__restrict__ src, int nch, int IH, int IW, int plane,
+                                            int pitch, int r0, int c0, int dil, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chs = IH * IW;
+    if (plane <= 64 * STAGE_MAXJ) {
+        const int J = (plane + 63) >> 6;
+        int goff[STAGE_MAXJ];
+#pragma unroll
+        for (int j = 0; j < STAGE_MAXJ; ++j) {
+            const int e = lane + 64 * j;
+            int off = -2;  // -2: beyond the plane, -1: zero padding
+            if (e < plane) {
+                const int r = e / pitch, cc = e - r * pitch;
+                int gy = r0 + r, gx = c0 + cc;
+                bool ok = gy >= 0 && gx >= 0;
+                if (dil == 2) {
+                    ok = ok && !((gy | gx) & 1);
+                    gy >>= 1;
+                    gx >>= 1;
+                }
+                ok = ok && gy < IH && gx < IW;
+                off = ok ? gy * IW + gx : -1;
+            }
+            goff[j] = off;
+        }
+        for (int cb = wave; cb < nch; cb += 16) {
+            float v[4][STAGE_MAXJ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + 4 * u;
+#pragma unroll
+                for (int j = 0; j < STAGE_MAXJ; ++j)
+                    if (j < J) v[u][j] = (c < nch && goff[j] >= 0) ? src[(long long)c * chs + goff[j]] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + 4 * u;
+#pragma unroll
+                for (int j = 0; j < STAGE_MAXJ; ++j)
+                    if (j < J && c < nch && goff[j] != -2) xs[c * plane + lane + 64 * j] = v[u][j];
+            }
+        }
+    } else {  // large planes (not produced by the tile shapes in use): generic element loop
+        const int total = nch * plane;
+        for (int e = tid; e < total; e += 256) {
+            const int c = e / plane, rem = e - c * plane;
+            const int r = rem / pitch, cc = rem - r * pitch;
+            int gy = r0 + r, gx = c0 + cc;
+            bool ok = gy >= 0 && gx >= 0;
+            if (dil == 2) {
+                ok = ok && !((gy | gx) & 1);
+                gy >>= 1;
+                gx >>= 1;
+            }
+            ok = ok && gy < IH && gx < IW;
+            xs[e] = ok ? src[((long long)c * IH + gy) * IW + gx] : 0.0f;
+        }
+    }
+}
 
 template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
@@ -84,24 +154,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
         for (int i = tid; i < a.L; i += 256) qs[i] = a.q[i];
 
     // ---- LDS image of the input tile (halo included, zero outside the tensor) -------------------
-    {
-        const int r0 = oy0 * a.rs - 1, c0 = ox0 * a.rs - 1;  // image origin in (dilated) input coordinates
-        const float *src = a.in + (long long)n * a.KC * a.IH * a.IW;
-        const int total = a.KC * a.plane;
-        for (int e = tid; e < total; e += 256) {
-            const int c = e / a.plane, rem = e - c * a.plane;
-            const int r = rem / a.pitch, cc = rem - r * a.pitch;
-            int gy = r0 + r, gx = c0 + cc;
-            bool ok = gy >= 0 && gx >= 0;
-            if (a.dil == 2) {
-                ok = ok && !((gy | gx) & 1);
-                gy >>= 1;
-                gx >>= 1;
-            }
-            ok = ok && gy < a.IH && gx < a.IW;
-            xs[e] = ok ? src[((long long)c * a.IH + gy) * a.IW + gx] : 0.0f;
-        }
-    }
+    stage_image(xs, a.in + (long long)n * a.KC * a.IH * a.IW, a.KC, a.IH, a.IW, a.plane, a.pitch, oy0 * a.rs - 1, ox0 * a.rs - 1, a.dil, tid);
     __syncthreads();
 
     // ---- per-lane pixel bases -------------------------------------------------------------------
@@ -122,12 +175,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkb = a.Kpad >> 4;
-    for (int kb = 0; kb < nkb; ++kb) {
+    // A fragments of k-block kb: 4 consecutive k per lane and m-tile
+    auto load_a = [&](int kb, float (&av)[MT][4]) {
         const int kbase = 16 * kb + 4 * kq;
-        const int4 ko = *reinterpret_cast<const int4 *>(&ktab[kbase]);
-        const int kof[4] = {ko.x, ko.y, ko.z, ko.w};
-        float av[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = m0 + 16 * m + jn;
@@ -152,16 +202,48 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
                 }
             }
         }
+    };
+
+    // Software pipeline over k-blocks (a wavefront often runs alone on its SIMD, so it hides its own
+    // latencies): while the MFMAs of block kb run, the B fragments and weights of kb+1 and the offset
+    // table entry of kb+2 are already in flight.
+    const int nkb = a.Kpad >> 4;
+    auto load_k = [&](int kb, int (&kof)[4]) {
+        const int4 ko = *reinterpret_cast<const int4 *>(&ktab[16 * (kb < nkb ? kb : nkb - 1) + 4 * kq]);
+        kof[0] = ko.x; kof[1] = ko.y; kof[2] = ko.z; kof[3] = ko.w;
+    };
+    auto load_b = [&](const int (&kof)[4], float (&bv)[4][NT]) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float bv[NT];
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = xs[pixbase[nt] + kof[t]];
+            for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
+    };
+    float av[MT][4], an[MT][4], bv[4][NT], bn[4][NT];
+    int kof1[4], kof2[4];
+    load_a(0, av);
+    load_k(0, kof1);
+    load_b(kof1, bv);
+    load_k(1, kof1);
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) {
+            load_a(kb + 1, an);
+            load_b(kof1, bn);
+        }
+        load_k(kb + 2, kof2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][t], bv[nt], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][t], bv[t][nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kof1[t] = kof2[t];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m][t] = an[m][t];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[t][nt] = bn[t][nt];
         }
     }
 
@@ -180,6 +262,240 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
         }
 }
 
+// Persistent variant of the forward / dgrad GEMM for tiles that span the whole output width
+// (all ResNet-20 shapes).  Per workgroup, ONCE: the k -> LDS-offset table and the weight panel of
+// its 16*MT output channels, stored in LDS in MFMA fragment order (one conflict-free ds_read_b128
+// per k-block and m-tile; hard-mode codes are decoded here).  Then it walks over tiles (image, row
+// band) with stride gridDim.x: the input of the NEXT tile is loaded into registers while the MFMAs
+// of the current tile run, and the main loop touches only LDS, so those loads stay in flight.
+// CH4 = input channels per wavefront, J = plane elements per lane.
+template <int MT, int NT, int CH4, int J, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *ktab = reinterpret_cast<int *>(smem);       // [Kpad]
+    float *As = smem + a.Kpad;                       // [Kpad/16][MT][64 lanes][4]
+    float *xs = As + MT * 16 * a.Kpad;               // [KC][rows_in][pitch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jn = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 16 * MT;
+
+    for (int k = tid; k < a.Kpad; k += 256) {
+        int off = 0;
+        if (k < a.K) {
+            const int c = k / 9, tap = k - 9 * c;
+            off = c * a.plane + (tap / 3) * a.pitch + (tap % 3);
+        }
+        ktab[k] = off;
+    }
+    // weight panel in fragment order: element (row rl, k) lives at
+    //   As[(((k>>4)*MT + (rl>>4))*64 + ((k>>2)&3)*16 + (rl&15))*4 + (k&3)]
+    // so the 4 consecutive k of one row form one 16-byte LDS store.  Work item = (row, group of 4 k);
+    // eight items per thread are loaded before the first store (the fill is latency-bound).
+    {
+        const int k4n = a.Kpad >> 2, items = 16 * MT * k4n;
+        for (int base = 0; base < items; base += 256 * 8) {
+            float4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * 256 + tid;
+                const int rl = it / k4n, k = (it - rl * k4n) * 4;
+                const int row = m0 + rl;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (it < items && row < a.M && k < a.K) {
+                    if (MODE == MODE_FWD && a.vecA) {
+                        v = *reinterpret_cast<const float4 *>(&a.W[(long long)row * a.K + k]);
+                    } else {
+                        float e[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int kk = k + t;
+                            float x = 0.0f;
+                            if (kk < a.K) {
+                                if (MODE == MODE_DGRAD) {
+                                    const int c = kk / 9, tap = kk - 9 * c;
+                                    x = a.W[(long long)c * a.Cin * 9 + row * 9 + (8 - tap)];  // W[co=c, ci=row, flipped tap]
+                                } else if (MODE == MODE_FWD_CODES) {
+                                    x = a.q[a.idx[(long long)row * a.K + kk]];
+                                } else {
+                                    x = a.W[(long long)row * a.K + kk];
+                                }
+                            }
+                            e[t] = x;
+                        }
+                        v = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
+                w[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * 256 + tid;
+                if (it < items) {
+                    const int rl = it / k4n, k = (it - rl * k4n) * 4;
+                    *reinterpret_cast<float4 *>(&As[(((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4]) = w[u];
+                }
+            }
+        }
+    }
+
+    // plane geometry of this lane's elements: row inside the image, input column (or -1)
+    int rj[J], gxj[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int e = lane + 64 * j;
+        const int r = (e * pitch_mul) >> 16;  // e / pitch, exact for e < 1024, pitch <= 65
+        int gx = e - r * a.pitch - 1;
+        bool ok = gx >= 0;
+        if (a.dil == 2) {
+            ok = ok && !(gx & 1);
+            gx >>= 1;
+        }
+        ok = ok && gx < a.IW;
+        rj[j] = e < a.plane ? r : -1;
+        gxj[j] = ok ? gx : -1;
+    }
+    // output pixels of this lane
+    int pixbase[NT], pyx[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int pr = (wave * NT + t) * 16 + jn;
+        const int py = pr >> tw_shift, px = pr & (a.TW - 1);
+        pixbase[t] = py * a.rs * a.pitch + px * a.rs;
+        pyx[t] = px < a.OW ? ((py << 16) | px) : -1;
+    }
+    const int chs = a.IH * a.IW;
+
+    float sv[CH4][J];
+    auto fetch_tile = [&](int tile) {
+        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
+        const int r0 = ty * a.TH * a.rs - 1;
+        const float *__restrict__ src = a.in + (long long)n * a.KC * chs;
+        int off[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            int gy = r0 + rj[j];
+            bool ok = rj[j] >= 0 && gxj[j] >= 0 && gy >= 0;
+            if (a.dil == 2) {
+                ok = ok && !(gy & 1);
+                gy >>= 1;
+            }
+            ok = ok && gy < a.IH;
+            off[j] = ok ? gy * a.IW + gxj[j] : -1;
+        }
+#ifdef AQ_EXPERIMENT
+        if (a.dbg & 2) return;
+#endif
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) {
+            const int c = wave + 4 * u;
+#pragma unroll
+            for (int j = 0; j < J; ++j) sv[u][j] = (c < a.KC && off[j] >= 0) ? src[(long long)c * chs + off[j]] : 0.0f;
+        }
+    };
+    auto commit_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) {
+            const int c = wave + 4 * u;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (c < a.KC && rj[j] >= 0) xs[c * a.plane + lane + 64 * j] = sv[u][j];
+        }
+    };
+
+    const int nkb = a.Kpad >> 4;
+    auto load_a = [&](int kb, float (&av)[MT][4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(&As[((kb * MT + m) * 64 + lane) * 4]);
+            av[m][0] = w4.x; av[m][1] = w4.y; av[m][2] = w4.z; av[m][3] = w4.w;
+        }
+    };
+    auto load_k = [&](int kb, int (&kof)[4]) {
+        const int4 ko = *reinterpret_cast<const int4 *>(&ktab[16 * (kb < nkb ? kb : nkb - 1) + 4 * kq]);
+        kof[0] = ko.x; kof[1] = ko.y; kof[2] = ko.z; kof[3] = ko.w;
+    };
+    auto load_b = [&](const int (&kof)[4], float (&bv)[4][NT]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        commit_tile();
+        __syncthreads();  // image (and, the first time, tables and weight panel) visible
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
+
+        floatx4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // Two register sets (0/1) alternate over k-blocks, the loop body has no branches and the number
+        // of k-blocks is even (K is padded with zero weights): while the MFMAs of one set run, the LDS
+        // reads of the other set are in flight, and the compiler can emit counted lgkmcnt waits.
+        float av0[MT][4], av1[MT][4], bv0[4][NT], bv1[4][NT];
+        int kofA[4], kofB[4];
+        auto mfmas = [&](const float (&av)[MT][4], const float (&bv)[4][NT]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][t], bv[t][nt], acc[m][nt], 0, 0, 0);
+        };
+        load_k(0, kofA);
+        load_k(1, kofB);
+        load_a(0, av0);
+        load_b(kofA, bv0);
+#ifdef AQ_EXPERIMENT
+        const int nkb_run = (a.dbg & 1) ? 0 : nkb;
+#else
+        const int nkb_run = nkb;
+#endif
+        for (int kb = 0; kb < nkb_run; kb += 2) {
+            // sched_barrier: keep each group of LDS reads ahead of the other set's MFMAs (the
+            // scheduler otherwise sinks the reads next to their consumers and the wave stalls)
+            load_a(kb + 1, av1);
+            load_b(kofB, bv1);
+            load_k(kb + 2, kofA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(av0, bv0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(kb + 2 < nkb ? kb + 2 : nkb - 1, av0);
+            load_b(kofA, bv0);
+            load_k(kb + 3, kofB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(av1, bv1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
+        const int oy0 = ty * a.TH;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+                if (pyx[nt] < 0 || oy >= a.OH) continue;
+#ifdef AQ_EXPERIMENT
+                if (a.dbg & 4) continue;
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = m0 + 16 * m + 4 * kq + r;
+                    if (ch < a.M) a.out[(((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox] = acc[m][nt][r];
+                }
+            }
+        __syncthreads();  // every wavefront is done with this tile's LDS image
+    }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 
 struct WgradArgs {
@@ -194,15 +510,19 @@ struct WgradArgs {
     int ngroups_img;             // ceil(N / IPB)
 };
 
+// Workgroup = 8 wavefronts: wavefronts 0-3 compute (MFMA), wavefronts 4-7 load.  The chunks of a
+// workgroup (TH x TW pixels of one image each) flow through two LDS buffers: while the compute
+// wavefronts work on chunk i, the loader wavefronts fill the other buffer with chunk i+1; one
+// barrier per chunk.  So global-memory latency is hidden behind the matrix work of the same CU.
 template <int MG, int NG>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int npix = a.TH * a.TW;
-    float *dys = smem;                           // [16*MG][cpitch]
-    float *xs = smem + 16 * MG * a.cpitch;       // [Cin][rows_in][pitch]
+    const int bufsz = 16 * MG * a.cpitch + a.Cin * a.plane;  // floats per buffer: dy tile, then x image
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const bool loader = threadIdx.x >= 256;
     const int jn = lane & 15, kq = lane >> 4;
 
     int bx = blockIdx.x;
@@ -213,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     const int m0 = blockIdx.y * 16 * MG;   // first output channel of this group
     const int j0 = blockIdx.z * 16 * NG;   // first (ci, tap) column of this group
 
-    // column (ci, tap) owned by this lane in each n-tile -> offset inside the x image
+    // compute wavefronts: column (ci, tap) owned by this lane in each n-tile -> offset inside the x image
     int joff[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -242,74 +562,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 
     const int r0 = oy0 * a.stride - 1, c0 = ox0 * a.stride - 1;
     const int nblk16 = npix >> 4;
-    for (int im = 0; im < a.IPB; ++im) {
-        const int n = ig * a.IPB + im;
-        if (n >= a.N) break;
-        __syncthreads();  // previous chunk fully consumed
-        // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout
-        {
-            const float *src = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
-            const int total = 16 * MG * npix;
-            for (int e = tid; e < total; e += 256) {
-                const int c = e / npix, pr = e - c * npix;
+    int nch = a.N - ig * a.IPB;
+    nch = nch < a.IPB ? nch : a.IPB;  // chunks (images) of this workgroup
+    for (int im = 0; im <= nch; ++im) {
+        if (loader) {
+            if (im < nch) {
+                const int n = ig * a.IPB + im;
+                float *dys = smem + (im & 1) * bufsz;
+                float *xs = dys + 16 * MG * a.cpitch;
+                // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout; a thread keeps
+                // its pixel (npix is 64 or 128: the same pixel for every channel it loads)
+                const float *src = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
+                const int pr = tid & (npix - 1), cstep = 256 / npix;
                 const int py = pr / a.TW, px = pr - py * a.TW;
-                const int oy = oy0 + py, ox = ox0 + px, co = m0 + c;
-                const bool ok = co < a.Cout && oy < a.Ho && ox < a.Wo;
-                dys[c * a.cpitch + pr] = ok ? src[((long long)co * a.Ho + oy) * a.Wo + ox] : 0.0f;
-            }
-        }
-        // x image with halo
-        {
-            const float *src = a.x + (long long)n * a.Cin * a.H * a.Wd;
-            const int total = a.Cin * a.plane;
-            for (int e = tid; e < total; e += 256) {
-                const int c = e / a.plane, rem = e - c * a.plane;
-                const int r = rem / a.pitch, cc = rem - r * a.pitch;
-                const int gy = r0 + r, gx = c0 + cc;
-                const bool ok = gy >= 0 && gx >= 0 && gy < a.H && gx < a.Wd;
-                xs[e] = ok ? src[((long long)c * a.H + gy) * a.Wd + gx] : 0.0f;
-            }
-        }
-        __syncthreads();
-        for (int pb = wave; pb < nblk16; pb += 4) {
-            const int p16 = pb * 16;
-            const int py = p16 / a.TW, px = p16 - py * a.TW;
-            const int bo = py * a.stride * a.pitch + px * a.stride;
+                const int oy = oy0 + py, ox = ox0 + px;
+                const int poff = (oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
+                const int chs = a.Ho * a.Wo;
+                // dy values wait in registers while the x image loads are issued behind them: one
+                // round trip to memory per chunk instead of two
+                float dv[8 * MG];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float av[MG], bv[NG];
+                for (int u = 0; u < 8 * MG; ++u) {
+                    const int c = tid / npix + cstep * u;
+                    const int co = m0 + c;
+                    dv[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
+                }
+                stage_image(xs, a.x + (long long)n * a.Cin * a.H * a.Wd, a.Cin, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
+#pragma unroll
+                for (int u = 0; u < 8 * MG; ++u) {
+                    const int c = tid / npix + cstep * u;
+                    if (c < 16 * MG) dys[c * a.cpitch + pr] = dv[u];
+                }
+            }
+        } else if (im >= 1) {
+            const float *dys = smem + ((im - 1) & 1) * bufsz;
+            const float *xs = dys + 16 * MG * a.cpitch;
+            // steps: (pixel block pb = wave, wave+4, ..) x (t = 0..3); two register sets alternate so that
+            // the LDS reads of the next step are in flight during the MFMAs of the current one
+            const int nsteps = ((nblk16 - wave + 3) >> 2) * 4;
+            float av0[MG], av1[MG], bv0[NG], bv1[NG];
+            auto load_step = [&](int sidx, float (&av)[MG], float (&bv)[NG]) {
+                const int s2 = sidx < nsteps ? sidx : nsteps - 1;
+                const int p16 = (wave + 4 * (s2 >> 2)) * 16, t = s2 & 3;
+                const int py = p16 / a.TW, px = p16 - py * a.TW;
+                const int bo = py * a.stride * a.pitch + px * a.stride + toff[t];
 #pragma unroll
                 for (int m = 0; m < MG; ++m) av[m] = dys[(16 * m + jn) * a.cpitch + p16 + 4 * t + kq];
 #pragma unroll
-                for (int g = 0; g < NG; ++g) bv[g] = xs[bo + toff[t] + joff[g]];
+                for (int g = 0; g < NG; ++g) bv[g] = xs[bo + joff[g]];
+            };
+            auto mfmas = [&](const float (&av)[MG], const float (&bv)[NG]) {
 #pragma unroll
                 for (int m = 0; m < MG; ++m)
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[g], acc[m][g], 0, 0, 0);
+            };
+            if (nsteps > 0) {
+                load_step(0, av0, bv0);
+                for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
+                    load_step(sidx + 1, av1, bv1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(av0, bv0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_step(sidx + 2, av0, bv0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(av1, bv1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
     }
 
-    // ---- sum the 4 wavefronts in LDS (fixed order 0+1+2+3), write the workgroup's slab ------------
+    // ---- sum the 4 compute wavefronts in LDS (fixed order 0+1+2+3), write the workgroup's slab ------
     float *part = a.part + (long long)blockIdx.x * a.Cout * a.K9;
     constexpr int TPR = 8;  // tiles per round: 8 tiles * 4 waves * 256 floats = 32 KiB
     float *red = smem;
     for (int base = 0; base < MG * NG; base += TPR) {
         __syncthreads();
+        if (!loader) {
 #pragma unroll
-        for (int m = 0; m < MG; ++m)
+            for (int m = 0; m < MG; ++m)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int tile = m * NG + g;
-                if (tile >= base && tile < base + TPR) {
-                    float *dst = red + (((tile - base) * 4 + wave) * 64 + lane) * 4;
-                    *reinterpret_cast<float4 *>(dst) = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+                for (int g = 0; g < NG; ++g) {
+                    const int tile = m * NG + g;
+                    if (tile >= base && tile < base + TPR) {
+                        float *dst = red + (((tile - base) * 4 + wave) * 64 + lane) * 4;
+                        *reinterpret_cast<float4 *>(dst) = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+                    }
                 }
-            }
+        }
         __syncthreads();
-        // 256 threads: thread = (tile-in-round tr = tid>>5? ) -> each thread sums one float4 of one tile per step
-        for (int e = tid; e < TPR * 64; e += 256) {
+        for (int e = threadIdx.x; e < TPR * 64; e += 512) {
             const int tr = e >> 6, ln = e & 63;
             const int tile = base + tr;
             if (tile >= MG * NG) break;
@@ -338,8 +683,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
     float s = 0.0f;
-    if (i < n)
-        for (int b = sg; b < nslab; b += 8) s += part[(long long)b * n + i];
+    if (i < n) {
+        int b = sg;
+        for (; b + 56 < nslab; b += 64) {  // eight independent loads in flight, added in ascending order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(b + 8 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nslab; b += 8) s += part[(long long)b * n + i];
+    }
     sh[sg][c] = s;
     __syncthreads();
     if (sg == 0 && i < n) {
@@ -389,14 +743,60 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
     a.pitch = (a.TW - 1) * a.rs + 3;
     a.rows_in = (a.TH - 1) * a.rs + 3;
     a.plane = a.rows_in * a.pitch;
-    a.Kpad = (a.K + 15) & ~15;
+    a.Kpad = (a.K + 31) & ~31;  // even number of 16-wide k-blocks (main loops are unrolled by two)
     a.vecA = (a.K % 4 == 0) && (((uintptr_t)a.W & 15) == 0);
+#ifdef AQ_EXPERIMENT
+    if (const char *e = getenv("AQ_CONV_DBG")) a.dbg = atoi(e);
+#endif
     size_t lds = (size_t)a.Kpad * 4 * (MODE == MODE_DGRAD ? 2 : 1) + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) * 4 : 0) +
                  (size_t)a.KC * a.plane * 4;
     AQ_REQUIRE(lds <= 64 * 1024, -E2BIG, "%s: input tile needs %zu bytes of LDS (limit 65536): too many channels", who, lds);
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     AQ_REQUIRE(gx < (1LL << 31), -E2BIG, "%s: grid too large", who);
-    dim3 grid((unsigned)gx, (unsigned)((mtiles + MT - 1) / MT));
+    const unsigned gy = (unsigned)((mtiles + MT - 1) / MT);
+    // persistent kernel: full-width tiles, channels and plane within the register-staging budget
+    const int CH4 = (a.KC + 3) / 4, J = (a.plane + 63) / 64;
+    const size_t plds = ((size_t)a.Kpad + (size_t)MT * 16 * a.Kpad + (size_t)a.KC * a.plane) * 4;
+    if (a.tiles_x == 1 && CH4 <= 16 && J <= 9 && CH4 * J <= 48 && a.pitch <= 65 && plds <= 160 * 1024) {
+        const int pitch_mul = (65536 + a.pitch - 1) / a.pitch;
+        int tw_shift = 0;
+        while ((1 << tw_shift) < a.TW) ++tw_shift;
+        // workgroups: as many as fit on the chip at once (LDS-limited, at most 2 per CU), each walking
+        // over its share of the tiles so that the weight panel is staged once per workgroup
+        const long long per_cu = std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)plds));
+        const long long want = std::max<long long>(1, 256 * per_cu / gy);
+        dim3 pgrid((unsigned)std::min<long long>(gx, want), gy);
+        const int c4 = CH4 <= 4 ? 4 : (CH4 <= 8 ? 8 : 16);
+        const int jj = J <= 2 ? 2 : (J <= 3 ? 3 : (J <= 5 ? 5 : 9));
+        bool done = true;
+#define AQ_P(MM, NN, CC, JJ)                                                                                                      \
+    {                                                                                                                             \
+        auto kern = conv_gemm_persist_kernel<MM, NN, CC, JJ, MODE>;                                                               \
+        if (plds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
+        hipLaunchKernelGGL(kern, pgrid, dim3(256), plds, st, a, (int)gx, pitch_mul, tw_shift);                                   \
+    }
+#define AQ_PJ(MM, NN, CC)                                 \
+        if (jj == 2) AQ_P(MM, NN, CC, 2)                  \
+        else if (jj == 3) AQ_P(MM, NN, CC, 3)             \
+        else if (jj == 5 && CC <= 8) AQ_P(MM, NN, CC, 5)  \
+        else if (jj == 9 && CC <= 4) AQ_P(MM, NN, CC, 9)  \
+        else done = false;
+#define AQ_PC(MM, NN)                          \
+        if (c4 == 4) { AQ_PJ(MM, NN, 4) }      \
+        else if (c4 == 8) { AQ_PJ(MM, NN, 8) } \
+        else { AQ_PJ(MM, NN, 16) }
+        if (MT == 4 && NT == 2) { AQ_PC(4, 2) }
+        else if (MT == 4) { AQ_PC(4, 1) }
+        else if (MT == 2 && NT == 2) { AQ_PC(2, 2) }
+        else if (MT == 2) { AQ_PC(2, 1) }
+        else if (NT == 2) { AQ_PC(1, 2) }
+        else { AQ_PC(1, 1) }
+#undef AQ_PC
+#undef AQ_PJ
+#undef AQ_P
+        if (done) return check_launch(who);
+    }
+    dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
     if (MT == 4 && NT == 2) AQ_GEMM(4, 2);
     else if (MT == 4) AQ_GEMM(4, 1);
@@ -463,13 +863,12 @@ static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &ld
     a.Wo = (a.Wd + 2 - 3) / a.stride + 1;
     a.K9 = a.Cin * 9;
     const int mtiles = (a.Cout + 15) / 16, ntiles = (a.K9 + 15) / 16;
-    // tile group kept in registers by every wavefront: MG x NG <= 36 tiles
+    // tile group kept in registers by every compute wavefront: MG x NG <= 18 tiles (72 accumulator
+    // registers + two operand sets fit the 256-register budget of an 8-wavefront workgroup)
     if (ntiles <= 3) NG = 3;
     else if (ntiles <= 9) NG = 9;
-    else if (ntiles <= 18) NG = 18;
-    else NG = 36;
-    MG = (NG <= 18 && mtiles >= 2) ? 2 : 1;
-    if (NG == 3 && MG == 2) MG = 1;
+    else NG = 18;
+    MG = (NG == 9 && mtiles >= 2) ? 2 : 1;
     pick_tile(a.Wo, 128, a.TW, a.TH);
     if ((long long)a.Ho * a.Wo <= 64) pick_tile(a.Wo, 64, a.TW, a.TH);
     a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
@@ -482,15 +881,15 @@ static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &ld
     // images per workgroup: keep >= ~256 workgroups in flight, at most 8 images each
     long long chunks = (long long)a.N * a.tiles_x * a.tiles_y;
     int ipb = 1;
-    while (ipb < 8 && chunks * gy * gz / (ipb * 2) >= 256 && ipb * 2 <= a.N) ipb *= 2;
+    while (ipb < 8 && chunks * gy * gz / (ipb * 2) >= 256 && ipb * 2 <= a.N) ipb *= 2;  // >= 256 workgroups
     a.IPB = ipb;
     a.ngroups_img = (a.N + ipb - 1) / ipb;
     const long long gx = (long long)a.ngroups_img * a.tiles_x * a.tiles_y;
     AQ_REQUIRE(gx < (1LL << 31) && gy < 65536 && gz < 65536, -E2BIG, "aq_conv_wgrad: grid too large");
     grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)gz);
-    lds = ((size_t)16 * MG * a.cpitch + (size_t)a.Cin * a.plane) * 4;
+    lds = 2 * ((size_t)16 * MG * a.cpitch + (size_t)a.Cin * a.plane) * 4;  // two chunk buffers
     lds = std::max(lds, (size_t)8 * 4 * 256 * 4);
-    AQ_REQUIRE(lds <= 64 * 1024, -E2BIG, "aq_conv_wgrad: tiles need %zu bytes of LDS (limit 65536): too many channels", lds);
+    AQ_REQUIRE(lds <= 160 * 1024, -E2BIG, "aq_conv_wgrad: tiles need %zu bytes of LDS (limit 163840): too many channels", lds);
     ws_bytes = (size_t)gx * a.Cout * a.K9 * 4;
     return 0;
 }
@@ -528,13 +927,16 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     size_t lds, ws;
     if (int rc = wgrad_plan(a, MG, NG, grid, lds, ws)) return rc;
     AQ_REQUIRE(workspace && workspace_bytes >= ws, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", ws, workspace_bytes);
-#define AQ_WG(MM, NN) hipLaunchKernelGGL((conv_wgrad_kernel<MM, NN>), grid, dim3(256), lds, st, a)
-    if (NG == 3) AQ_WG(1, 3);
-    else if (NG == 9 && MG == 1) AQ_WG(1, 9);
-    else if (NG == 9) AQ_WG(2, 9);
-    else if (NG == 18 && MG == 1) AQ_WG(1, 18);
-    else if (NG == 18) AQ_WG(2, 18);
-    else AQ_WG(1, 36);
+#define AQ_WG(MM, NN)                                                                                                          \
+    {                                                                                                                          \
+        auto kern = conv_wgrad_kernel<MM, NN>;                                                                                 \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                                 \
+    }
+    if (NG == 3) AQ_WG(1, 3)
+    else if (NG == 9 && MG == 1) AQ_WG(1, 9)
+    else if (NG == 9) AQ_WG(2, 9)
+    else AQ_WG(1, 18)
 #undef AQ_WG
     if (int rc = check_launch("aq_conv_wgrad")) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, a.part, dW, nW, (int)grid.x);
