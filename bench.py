@@ -66,20 +66,25 @@ def kernel_rooflines(quick):
     dp = [torch.empty_like(p)]
     t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20)
     t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 10)
-    traffic = None
+    # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc on the same
+    # 250 M-element tensor, see profiles/roofline_traffic.json); only valid for the full-size tensor
+    traffic = traffic2 = None
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tf):
+    if os.path.exists(tf) and not quick:
         try:
-            traffic = json.load(open(tf)).get("synth_fwd_bytes_per_launch")
+            tj = json.load(open(tf))
+            if tj.get("rows_per_launch") == rows:
+                traffic, traffic2 = tj.get("synth_fwd_bytes_per_launch"), tj.get("synth_bwd_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic = traffic2 = None
     a1 = rows * (4 * L + 4) / t1 / 1e9
-    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8,true,false>", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
-    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8,true>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(a2 / HBM_PEAK_GBS, 4), "bytes_per_row": 8 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t2 * 1e3, 4)}]
+    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": traffic2, "bytes_per_row": 8 * L + 4, "rows_per_launch": rows,
+             "avg_launch_ms": round(t2 * 1e3, 4)}]
     del p, dW, W, dp
     torch.cuda.empty_cache()
     for (cin, cout, s, H) in [(16, 16, 1, 32), (16, 32, 2, 32), (32, 32, 1, 16), (32, 64, 2, 16), (64, 64, 1, 8)]:
