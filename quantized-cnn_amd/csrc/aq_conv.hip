@@ -514,7 +514,10 @@ struct WgradArgs {
 // workgroup (TH x TW pixels of one image each) flow through two LDS buffers: while the compute
 // wavefronts work on chunk i, the loader wavefronts fill the other buffer with chunk i+1; one
 // barrier per chunk.  So global-memory latency is hidden behind the matrix work of the same CU.
-template <int MG, int NG>
+// CH4 > 0 (tiles spanning the output width): the loader wavefronts keep the next chunk in registers
+// (CH4 input channels per wavefront, J image elements per lane) for one phase before writing it to
+// LDS, so their loads are in flight during a whole compute phase.  CH4 == 0: generic loader.
+template <int MG, int NG, int CH4, int J>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -564,34 +567,89 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     const int nblk16 = npix >> 4;
     int nch = a.N - ig * a.IPB;
     nch = nch < a.IPB ? nch : a.IPB;  // chunks (images) of this workgroup
+
+    // loader state (register-staged variant): the tile position is fixed for the workgroup, only the
+    // image changes from chunk to chunk, so all offsets are computed once
+    constexpr int CH4R = CH4 > 0 ? CH4 : 1, JR = CH4 > 0 ? J : 1;
+    int xoff[JR];
+    float sv[CH4R][JR], dvr[8 * MG];
+    const int pr = tid & (npix - 1), cstep = 256 / npix;
+    int poff = -1;
+    if (loader) {
+        const int py = pr / a.TW, px = pr - py * a.TW;
+        const int oy = oy0 + py, ox = ox0 + px;
+        poff = (oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
+        if (CH4 > 0) {
+#pragma unroll
+            for (int j = 0; j < JR; ++j) {
+                const int e = lane + 64 * j;
+                const int r = e / a.pitch, cc = e - r * a.pitch;
+                const int gy = r0 + r, gx = c0 + cc;
+                const bool ok = e < a.plane && gy >= 0 && gx >= 0 && gy < a.H && gx < a.Wd;
+                xoff[j] = ok ? gy * a.Wd + gx : (e < a.plane ? -1 : -2);
+            }
+        }
+    }
+    auto fetch_chunk = [&](int im) {
+        const int n = ig * a.IPB + im;
+        const float *__restrict__ sdy = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
+        const float *__restrict__ sx = a.x + (long long)n * a.Cin * a.H * a.Wd;
+        const int chs = a.Ho * a.Wo, xchs = a.H * a.Wd;
+#pragma unroll
+        for (int u = 0; u < 8 * MG; ++u) {
+            const int c = tid / npix + cstep * u;
+            const int co = m0 + c;
+            dvr[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? sdy[(long long)co * chs + poff] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < CH4R; ++u) {
+            const int c = wave + 4 * u;
+#pragma unroll
+            for (int j = 0; j < JR; ++j) sv[u][j] = (c < a.Cin && xoff[j] >= 0) ? sx[(long long)c * xchs + xoff[j]] : 0.0f;
+        }
+    };
+    auto commit_chunk = [&](int im) {
+        float *dys = smem + (im & 1) * bufsz;
+        float *xs = dys + 16 * MG * a.cpitch;
+#pragma unroll
+        for (int u = 0; u < 8 * MG; ++u) {
+            const int c = tid / npix + cstep * u;
+            if (c < 16 * MG) dys[c * a.cpitch + pr] = dvr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < CH4R; ++u) {
+            const int c = wave + 4 * u;
+#pragma unroll
+            for (int j = 0; j < JR; ++j)
+                if (c < a.Cin && xoff[j] != -2) xs[c * a.plane + lane + 64 * j] = sv[u][j];
+        }
+    };
+    if (CH4 > 0 && loader && nch > 0) fetch_chunk(0);
+
     for (int im = 0; im <= nch; ++im) {
         if (loader) {
-            if (im < nch) {
+            if (CH4 > 0) {
+                if (im < nch) commit_chunk(im);          // loaded during the previous phase
+                if (im + 1 < nch) fetch_chunk(im + 1);   // lands during the next compute phase
+            } else if (im < nch) {
                 const int n = ig * a.IPB + im;
                 float *dys = smem + (im & 1) * bufsz;
                 float *xs = dys + 16 * MG * a.cpitch;
-                // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout; a thread keeps
-                // its pixel (npix is 64 or 128: the same pixel for every channel it loads)
+                // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout; the dy values
+                // wait in registers while the x image loads are issued behind them (one round trip)
                 const float *src = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
-                const int pr = tid & (npix - 1), cstep = 256 / npix;
-                const int py = pr / a.TW, px = pr - py * a.TW;
-                const int oy = oy0 + py, ox = ox0 + px;
-                const int poff = (oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
                 const int chs = a.Ho * a.Wo;
-                // dy values wait in registers while the x image loads are issued behind them: one
-                // round trip to memory per chunk instead of two
-                float dv[8 * MG];
 #pragma unroll
                 for (int u = 0; u < 8 * MG; ++u) {
                     const int c = tid / npix + cstep * u;
                     const int co = m0 + c;
-                    dv[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
+                    dvr[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
                 }
                 stage_image(xs, a.x + (long long)n * a.Cin * a.H * a.Wd, a.Cin, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
 #pragma unroll
                 for (int u = 0; u < 8 * MG; ++u) {
                     const int c = tid / npix + cstep * u;
-                    if (c < 16 * MG) dys[c * a.cpitch + pr] = dv[u];
+                    if (c < 16 * MG) dys[c * a.cpitch + pr] = dvr[u];
                 }
             }
         } else if (im >= 1) {
@@ -618,17 +676,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
                     for (int g = 0; g < NG; ++g)
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[g], acc[m][g], 0, 0, 0);
             };
-            if (nsteps > 0) {
-                load_step(0, av0, bv0);
-                for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
-                    load_step(sidx + 1, av1, bv1);
-                    __builtin_amdgcn_sched_barrier(0);
+            if (MG * NG <= 9) {
+                if (nsteps > 0) {
+                    load_step(0, av0, bv0);
+                    for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
+                        load_step(sidx + 1, av1, bv1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(av0, bv0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_step(sidx + 2, av0, bv0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(av1, bv1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {  // large tile groups: one operand set (register budget), 18 MFMAs cover the reads
+                for (int sidx = 0; sidx < nsteps; ++sidx) {
+                    load_step(sidx, av0, bv0);
                     mfmas(av0, bv0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_step(sidx + 2, av0, bv0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfmas(av1, bv1);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -927,16 +992,38 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     size_t lds, ws;
     if (int rc = wgrad_plan(a, MG, NG, grid, lds, ws)) return rc;
     AQ_REQUIRE(workspace && workspace_bytes >= ws, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", ws, workspace_bytes);
-#define AQ_WG(MM, NN)                                                                                                          \
+    // register-staged loader when the tile spans the output width and the image fits the budget
+    const int c4 = (a.Cin + 3) / 4, jx = (a.plane + 63) / 64;
+    int variant = 0;
+    if (a.tiles_x == 1) {
+        if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) variant = 1;
+        else if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) variant = 2;
+        else if (NG == 18 && c4 <= 8 && jx <= 3) variant = 3;
+        else if (NG == 18 && c4 <= 8 && jx <= 5) variant = 4;
+        else if (NG == 18 && c4 <= 16 && jx <= 2) variant = 5;
+    }
+#define AQ_WGV(MM, NN, CC, JJ)                                                                                                 \
     {                                                                                                                          \
-        auto kern = conv_wgrad_kernel<MM, NN>;                                                                                 \
+        auto kern = conv_wgrad_kernel<MM, NN, CC, JJ>;                                                                         \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                                 \
     }
-    if (NG == 3) AQ_WG(1, 3)
+#define AQ_WG(MM, NN)                                                                                                          \
+    {                                                                                                                          \
+        auto kern = conv_wgrad_kernel<MM, NN, 0, 1>;                                                                                 \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                                 \
+    }
+    if (variant == 1) AQ_WGV(1, 9, 4, 4)
+    else if (variant == 2) AQ_WGV(2, 9, 4, 9)
+    else if (variant == 3) AQ_WGV(1, 18, 8, 3)
+    else if (variant == 4) AQ_WGV(1, 18, 8, 5)
+    else if (variant == 5) AQ_WGV(1, 18, 16, 2)
+    else if (NG == 3) AQ_WG(1, 3)
     else if (NG == 9 && MG == 1) AQ_WG(1, 9)
     else if (NG == 9) AQ_WG(2, 9)
     else AQ_WG(1, 18)
+#undef AQ_WGV
 #undef AQ_WG
     if (int rc = check_launch("aq_conv_wgrad")) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, a.part, dW, nW, (int)grid.x);
