@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 2
+#define AQ_ABI_VERSION 3
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -73,6 +73,11 @@ size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward);
  * adp_qtz_fan.py:574-601 (== cross-correlation).  W is [Cout, Cin, 3, 3]. */
 int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H, int Wd, int Cout,
                 int ksize, int stride, int pad, void *stream);
+/* y = conv(x, W) + res: the convolution and the shortcut addition that follows it in every block
+ * (`out = self.conv2(out); out += self.shortcut(x)`, adp_qtz_fan.py:676-677, 691-692).  res has the
+ * shape of y and may alias it. */
+int aq_conv_fwd_add(const float *x, const float *W, const float *res, float *y, int N, int Cin, int H,
+                    int Wd, int Cout, int ksize, int stride, int pad, void *stream);
 /* same, weights given as codes + levels (hard mode, adp_qtz_fan_test.py:304-331): W = q[idx] is
  * decoded while the weight tile is staged into LDS. */
 int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L, float *y, int N,
@@ -94,6 +99,31 @@ int aq_linear_fwd(const float *x, const float *W, const float *bias, float *y, i
                   void *stream);
 int aq_linear_bwd(const float *x, const float *W, const float *dy, float *dx, float *dW, float *dbias,
                   int N, int In, int Out, void *stream);
+
+/* Batch normalisation over (N, H*W) of an NCHW tensor fused with the ReLU that follows it in the
+ * reference's blocks: `F.relu(self.bn1(x))`, `F.relu(self.bn2(self.conv1(out)))`
+ * (adp_qtz_fan.py:674-675, 690, 726, 730; the modules are nn.BatchNorm2d, :661-663, 686, 700, 707).
+ * Batch-statistics mode (default): y = [relu](gamma*(x-mean)*rstd + beta) with the biased batch
+ * variance, stores mean and rstd = 1/sqrt(var+eps) in save_mean / save_rstd [C] for the backward
+ * pass and, when running_mean / running_var are given, updates them as nn.BatchNorm2d does
+ * (r += momentum*(batch - r), unbiased variance; *num_batches_tracked += 1 when non-NULL).
+ * AQ_BN_EVAL: normalise with the running statistics instead (save_*, workspace unused).
+ * workspace: aq_bn_workspace_bytes(N, C, HW) bytes. */
+#define AQ_BN_RELU 1u
+#define AQ_BN_EVAL 2u
+int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                   float *running_var, long long *num_batches_tracked, int N, int C, int HW, float eps,
+                   float momentum, unsigned flags, float *y, float *save_mean, float *save_rstd,
+                   void *workspace, size_t workspace_bytes, void *stream);
+/* Gradient of the above in batch-statistics mode: dy is d loss / d y; dx = d loss / d x [+ res when
+ * res != NULL: the gradient arriving over the block's shortcut, `out + x` adp_qtz_fan.py:677, 692],
+ * dgamma[C], dbeta[C] (either may be NULL).  x, gamma, beta must be unchanged since the forward call
+ * (the ReLU mask is recomputed from them).  dx may alias dy or res. */
+int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
+                   const float *save_mean, const float *save_rstd, const float *res, int N, int C, int HW,
+                   unsigned flags, float *dx, float *dgamma, float *dbeta, void *workspace,
+                   size_t workspace_bytes, void *stream);
+size_t aq_bn_workspace_bytes(int N, int C, int HW);
 
 #ifdef __cplusplus
 }

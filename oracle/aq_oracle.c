@@ -336,6 +336,74 @@ void aqo_linear_bwd(const float *x, const float *W, const float *dy, int N, int 
         }
 }
 
+/* ---- batch normalisation (+ReLU) ------------------------------------------------------------
+ * `F.relu(self.bnX(x))` with nn.BatchNorm2d in training mode (adp_qtz_fan.py:661-663, 674-675, 690,
+ * 726, 730): per channel c over (N, HW): mean, biased variance, y = gamma*(x-mean)/sqrt(var+eps)+beta,
+ * then max(0, .).  Statistics are accumulated in double.  stats[c] = {mean, rstd, unbiased var}. */
+void aqo_bn_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int Cn, int HW,
+                     float eps, int relu, float *y, double *stats)
+{
+    for (int c = 0; c < Cn; ++c) {
+        double s = 0.0, m2 = 0.0;
+        const double cnt = (double)N * HW;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) s += x[((size_t)n * Cn + c) * HW + i];
+        const double mean = s / cnt;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) {
+                const double d = x[((size_t)n * Cn + c) * HW + i] - mean;
+                m2 += d * d;
+            }
+        const double rstd = 1.0 / sqrt(m2 / cnt + (double)eps);
+        stats[3 * c] = mean;
+        stats[3 * c + 1] = rstd;
+        stats[3 * c + 2] = cnt > 1 ? m2 / (cnt - 1) : m2;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) {
+                const size_t o = ((size_t)n * Cn + c) * HW + i;
+                const double t = (x[o] - mean) * rstd * gamma[c] + beta[c];
+                y[o] = (float)((relu && t < 0.0) ? 0.0 : t);
+            }
+    }
+}
+
+/* gradient of the above (autograd of batch_norm + relu): g = dy*[y>0],
+ * dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (+res), dgamma = sum g*xhat, dbeta = sum g */
+void aqo_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *res,
+                     int N, int Cn, int HW, float eps, int relu, float *dx, float *dgamma, float *dbeta)
+{
+    for (int c = 0; c < Cn; ++c) {
+        double s = 0.0, m2 = 0.0, s1 = 0.0, s2 = 0.0;
+        const double cnt = (double)N * HW;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) s += x[((size_t)n * Cn + c) * HW + i];
+        const double mean = s / cnt;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) {
+                const double d = x[((size_t)n * Cn + c) * HW + i] - mean;
+                m2 += d * d;
+            }
+        const double rstd = 1.0 / sqrt(m2 / cnt + (double)eps);
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) {
+                const size_t o = ((size_t)n * Cn + c) * HW + i;
+                const double xh = (x[o] - mean) * rstd;
+                const double g = (!relu || xh * gamma[c] + beta[c] > 0.0) ? dy[o] : 0.0;
+                s1 += g;
+                s2 += g * xh;
+            }
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < HW; ++i) {
+                const size_t o = ((size_t)n * Cn + c) * HW + i;
+                const double xh = (x[o] - mean) * rstd;
+                const double g = (!relu || xh * gamma[c] + beta[c] > 0.0) ? dy[o] : 0.0;
+                dx[o] = (float)(gamma[c] * rstd * (g - s1 / cnt - xh * s2 / cnt) + (res ? res[o] : 0.0));
+            }
+    }
+}
+
 int aqo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -39,10 +39,12 @@ def lib():
         L.aqo_conv_wgrad.argtypes = conv
         L.aqo_linear_fwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp]
         L.aqo_linear_bwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp]
+        L.aqo_bn_relu_fwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, dp]
+        L.aqo_bn_relu_bwd.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp]
         L.aqo_num_threads.restype = C.c_int
         L.aqo_set_num_threads.argtypes = [C.c_int]
         for f in ("aqo_synth_fwd", "aqo_synth_bwd", "aqo_conv_fwd", "aqo_conv_dgrad", "aqo_conv_wgrad",
-                  "aqo_linear_fwd", "aqo_linear_bwd", "aqo_set_num_threads"):
+                  "aqo_linear_fwd", "aqo_linear_bwd", "aqo_set_num_threads", "aqo_bn_relu_fwd", "aqo_bn_relu_bwd"):
             getattr(L, f).restype = None
         _LIB = L
     return _LIB
@@ -164,6 +166,36 @@ def linear_bwd(x, W, dy):
 
 
 # ---- level initialisers (host logic of the reference, restated) -------------------------------
+
+def bn_relu_fwd(x, gamma, beta, eps=1e-5, relu=True):
+    """-> y, mean (C,), rstd (C,), unbiased variance (C,) (float64 statistics)."""
+    xa, xp = _f(x)
+    ga, gp = _f(gamma)
+    ba, bp = _f(beta)
+    N, Cn = xa.shape[0], xa.shape[1]
+    HW = xa.size // (N * Cn)
+    y = np.empty_like(xa)
+    st = np.zeros((Cn, 3), np.float64)
+    lib().aqo_bn_relu_fwd(xp, gp, bp, N, Cn, HW, float(eps), int(relu), y.ctypes.data_as(C.POINTER(C.c_float)),
+                          st.ctypes.data_as(C.POINTER(C.c_double)))
+    return y, st[:, 0].copy(), st[:, 1].copy(), st[:, 2].copy()
+
+
+def bn_relu_bwd(dy, x, gamma, beta, res=None, eps=1e-5, relu=True):
+    """-> dx (+res), dgamma, dbeta"""
+    da, dyp = _f(dy)
+    xa, xp = _f(x)
+    ga, gp = _f(gamma)
+    ba, bp = _f(beta)
+    ra, rp = _f(res) if res is not None else (None, None)
+    N, Cn = xa.shape[0], xa.shape[1]
+    HW = xa.size // (N * Cn)
+    fp = C.POINTER(C.c_float)
+    dx, dg, db = np.empty_like(xa), np.empty(Cn, np.float32), np.empty(Cn, np.float32)
+    lib().aqo_bn_relu_bwd(dyp, xp, gp, bp, rp, N, Cn, HW, float(eps), int(relu), dx.ctypes.data_as(fp), dg.ctypes.data_as(fp),
+                          db.ctypes.data_as(fp))
+    return dx, dg, db
+
 
 def levels_fix(s, num_level, liar=True):
     """adp_qtz_fix.py:661-665: [-2^t .. descending magnitude], 0, [2^t ..]; num_level-1 entries."""

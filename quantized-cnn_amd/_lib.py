@@ -11,14 +11,15 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_EXACT = 1
+BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
 
 EXPORTS = (
     "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
-    "aq_linear_fwd", "aq_linear_bwd",
+    "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
 )
 
 
@@ -50,6 +51,7 @@ def lib():
         L.aq_synth_workspace_bytes.restype = sz
         conv_dims = [i] * 8
         L.aq_conv_fwd.argtypes = [vp, vp, vp] + conv_dims + [vp]
+        L.aq_conv_fwd_add.argtypes = [vp, vp, vp, vp] + conv_dims + [vp]
         L.aq_conv_fwd_codes.argtypes = [vp, vp, vp, i, vp] + conv_dims + [vp]
         L.aq_conv_dgrad.argtypes = [vp, vp, vp] + conv_dims + [vp]
         L.aq_conv_wgrad.argtypes = [vp, vp, vp] + conv_dims + [vp, sz, vp]
@@ -57,8 +59,12 @@ def lib():
         L.aq_conv_wgrad_workspace_bytes.restype = sz
         L.aq_linear_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
         L.aq_linear_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
-        for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad",
-                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd"):
+        L.aq_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, f, C.c_uint, vp, vp, vp, vp, sz, vp]
+        L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, vp]
+        L.aq_bn_workspace_bytes.argtypes = [i, i, i]
+        L.aq_bn_workspace_bytes.restype = sz
+        for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",
+                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd"):
             getattr(L, name).restype = i
         if L.aq_abi_version() != ABI_VERSION:
             raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))

@@ -42,9 +42,7 @@ class Residual(layers._Block):
         self.shortcut = self._shortcut(in_channel, increase_dim)
 
     def forward(self, x):
-        out = self.conv1(nn.functional.relu(self.bn1(x)))
-        out = self.conv2(nn.functional.relu(self.bn2(out)))
-        return out + self.shortcut(x)
+        return self._residual_forward(x)
 
 
 class PreResidual(layers._Block):
@@ -55,8 +53,7 @@ class PreResidual(layers._Block):
         self.conv2 = MyConv2d(config, s2, in_channel, in_channel, ksize=3, stride=1, padding=1, bias=False)
 
     def forward(self, x):
-        out = self.conv2(nn.functional.relu(self.bn2(self.conv1(x))))
-        return out + x
+        return self._preresidual_forward(x)
 
 
 class ResNet(layers.QResNet):

@@ -1,0 +1,345 @@
+// Batch normalisation over (N, H, W) of an NCHW fp32 tensor fused with the ReLU that follows it
+// everywhere in the reference's ResNet (`F.relu(self.bnX(..))`, adp_qtz_fan.py:674-675, 690, 726,
+// 730), forward and backward, with the residual gradient added in the backward output pass.
+//
+// Both directions are two launches over a (blocks per channel, channel) grid:
+//   forward   stats:  every block reduces its slice of one channel to (mean, sum of squared
+//                     deviations from that mean) -- two passes over a slice that stays in cache,
+//                     so no E[x^2]-E[x]^2 cancellation;
+//             apply:  every block merges the channel's partials (fixed order, one wavefront),
+//                     derives scale = gamma*rstd, shift = beta - mean*scale and writes
+//                     y = max(0, x*scale + shift); block 0 of the channel also stores mean / rstd and
+//                     updates the running statistics;
+//   backward  reduce: partial sums of g and g*xhat with g = dy*[y > 0];
+//             apply:  dx = scale*(g - mean(g) - xhat*mean(g*xhat)) [+ res]; block 0 stores dgamma, dbeta.
+// No atomics, fixed summation order: results are reproducible run to run.  The tensors of ResNet-20
+// (<= 8.4 MB) stay in L2 / Infinity Cache between the two launches; the kernels are bandwidth- and
+// launch-bound.
+#include "aq_common.h"
+#include "../../include/aq_hip.h"
+
+namespace aq {
+
+constexpr int BN_T = 256;
+constexpr int BN_MAX_PARTS = 64;  // partial blocks per channel (merged by one wavefront)
+
+struct BnGeom {
+    int N, C, HW;
+    int S, npb;    // reduction launches: S blocks per channel, npb images per block
+    int S2, npb2;  // streaming launches
+};
+
+static BnGeom bn_geom(int N, int C, int HW)
+{
+    BnGeom g{N, C, HW, 1, 1, 1, 1};
+    int npb = HW >= 2048 ? 1 : 2048 / HW;
+    g.npb2 = npb;
+    g.S2 = (N + npb - 1) / npb;
+    const int cap = (N + BN_MAX_PARTS - 1) / BN_MAX_PARTS;
+    g.npb = npb > cap ? npb : cap;
+    g.S = (N + g.npb - 1) / g.npb;
+    return g;
+}
+
+typedef float vec4 __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+    vec4 v;
+    __device__ static Vec load(const float *p) { return Vec{*reinterpret_cast<const vec4 *>(p)}; }
+    __device__ void store(float *p) const { *reinterpret_cast<vec4 *>(p) = v; }
+    __device__ float &operator[](int i) { return reinterpret_cast<float *>(&v)[i]; }
+};
+template <> struct Vec<1> {
+    float v;
+    __device__ static Vec load(const float *p) { return Vec{*p}; }
+    __device__ void store(float *p) const { *p = v; }
+    __device__ float &operator[](int) { return v; }
+};
+
+__device__ inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// sum over the 256 threads of a block, result in every thread; sh holds 4 floats
+__device__ inline float block_sum(float v, float *sh)
+{
+    v = wave_sum(v);
+    __syncthreads();  // protects sh against the previous use
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__device__ inline void scale_shift(float gamma, float beta, float mean, float rstd, float &scale, float &shift)
+{
+    scale = gamma * rstd;
+    shift = __builtin_fmaf(-mean, scale, beta);
+}
+
+// iterate over the vectors of channel c in images [n0, n1): f(offset into the tensor)
+template <int VEC, typename F>
+__device__ inline void for_slice(int n0, int n1, int c, int C, int HW, F f)
+{
+    const int per = HW / VEC;
+    const int total = (n1 - n0) * per;
+    for (int i = threadIdx.x; i < total; i += BN_T) {
+        const int n = i / per, k = i - n * per;
+        f(((size_t)(n0 + n) * C + c) * HW + (size_t)k * VEC);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict__ x, float2 *__restrict__ part, BnGeom g)
+{
+    __shared__ float sh[4];
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int n0 = s * g.npb, n1 = min(g.N, n0 + g.npb);
+    const float cnt = (float)(n1 - n0) * (float)g.HW;
+    float a = 0.0f;
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+        auto v = Vec<VEC>::load(x + o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a += v[j];
+    });
+    const float mean = block_sum(a, sh) / cnt;
+    float m2 = 0.0f;
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+        auto v = Vec<VEC>::load(x + o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float d = v[j] - mean;
+            m2 = __builtin_fmaf(d, d, m2);
+        }
+    });
+    m2 = block_sum(m2, sh);
+    if (threadIdx.x == 0) part[c * g.S + s] = make_float2(mean, m2);
+}
+
+struct BnApplyArgs {
+    const float *x;
+    float *y;
+    const float2 *part;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;
+    float *save_mean, *save_rstd;
+    float eps, momentum;
+    int eval;
+};
+
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
+{
+    __shared__ float sc[2];
+    const int c = blockIdx.y;
+    if (threadIdx.x < 64) {
+        float mean, rstd;
+        if (a.eval) {
+            mean = a.running_mean[c];
+            rstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+        } else {
+            // merge the S partials: mean = sum n_s mean_s / n, M2 = sum M2_s + sum n_s (mean_s - mean)^2
+            const int s = threadIdx.x;
+            const bool on = s < g.S;
+            const float2 p = on ? a.part[c * g.S + s] : make_float2(0.0f, 0.0f);
+            const float ns = on ? (float)(min(g.N, (s + 1) * g.npb) - s * g.npb) * (float)g.HW : 0.0f;
+            const float cnt = (float)g.N * (float)g.HW;
+            mean = wave_sum(ns * p.x) / cnt;
+            const float d = p.x - mean;
+            const float M2 = wave_sum(p.y + ns * d * d);
+            const float var = M2 / cnt;
+            rstd = 1.0f / sqrtf(var + a.eps);
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                a.save_mean[c] = mean;
+                a.save_rstd[c] = rstd;
+                if (a.running_mean) {
+                    const float unbiased = M2 / fmaxf(cnt - 1.0f, 1.0f);
+                    a.running_mean[c] = __builtin_fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
+                    a.running_var[c] = __builtin_fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
+                }
+                if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+            }
+        }
+        if (threadIdx.x == 0) scale_shift(a.gamma[c], a.beta[c], mean, rstd, sc[0], sc[1]);
+    }
+    __syncthreads();
+    const float scale = sc[0], shift = sc[1];
+    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+        auto v = Vec<VEC>::load(a.x + o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float t = __builtin_fmaf(v[j], scale, shift);
+            v[j] = RELU ? fmaxf(t, 0.0f) : t;
+        }
+        v.store(a.y + o);
+    });
+}
+
+struct BnBwdArgs {
+    const float *dy, *x, *res;
+    float *dx;
+    float2 *part;
+    const float *gamma, *beta, *save_mean, *save_rstd;
+    float *dgamma, *dbeta;
+};
+
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(BnBwdArgs a, BnGeom g)
+{
+    __shared__ float sh[4];
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int n0 = s * g.npb, n1 = min(g.N, n0 + g.npb);
+    const float mean = a.save_mean[c], rstd = a.save_rstd[c];
+    float scale, shift;
+    scale_shift(a.gamma[c], a.beta[c], mean, rstd, scale, shift);
+    float s1 = 0.0f, s2 = 0.0f;
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+        auto d = Vec<VEC>::load(a.dy + o);
+        auto v = Vec<VEC>::load(a.x + o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool live = !RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f;
+            const float gq = live ? d[j] : 0.0f;
+            s1 += gq;
+            s2 = __builtin_fmaf(gq, (v[j] - mean) * rstd, s2);
+        }
+    });
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) a.part[c * g.S + s] = make_float2(s1, s2);
+}
+
+template <int VEC, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom g)
+{
+    __shared__ float sc[2];
+    const int c = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const int s = threadIdx.x;
+        const float2 p = s < g.S ? a.part[c * g.S + s] : make_float2(0.0f, 0.0f);
+        const float s1 = wave_sum(p.x), s2 = wave_sum(p.y);
+        if (threadIdx.x == 0) {
+            sc[0] = s1;
+            sc[1] = s2;
+            if (blockIdx.x == 0) {
+                if (a.dbeta) a.dbeta[c] = s1;
+                if (a.dgamma) a.dgamma[c] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    const float cnt = (float)g.N * (float)g.HW;
+    const float k1 = sc[0] / cnt, k2 = sc[1] / cnt;
+    const float mean = a.save_mean[c], rstd = a.save_rstd[c];
+    float scale, shift;
+    scale_shift(a.gamma[c], a.beta[c], mean, rstd, scale, shift);
+    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+        auto d = Vec<VEC>::load(a.dy + o);
+        auto v = Vec<VEC>::load(a.x + o);
+        Vec<VEC> r;
+        if (RES) r = Vec<VEC>::load(a.res + o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool live = !RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f;
+            const float gq = live ? d[j] : 0.0f;
+            const float xh = (v[j] - mean) * rstd;
+            float t = scale * ((gq - k1) - xh * k2);
+            if (RES) t += r[j];
+            d[j] = t;
+        }
+        d.store(a.dx + o);
+    });
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_dims(const char *fn, int N, int C, int HW, bool batch_stats)
+{
+    AQ_REQUIRE(N >= 1 && C >= 1 && HW >= 1, -EINVAL, "%s: bad sizes N=%d C=%d HW=%d", fn, N, C, HW);
+    AQ_REQUIRE(C <= 65535, -E2BIG, "%s: more than 65535 channels", fn);
+    AQ_REQUIRE((long long)N * HW < (1LL << 31), -E2BIG, "%s: N*H*W too large", fn);
+    AQ_REQUIRE(!batch_stats || (long long)N * HW >= 2, -EINVAL, "%s: batch statistics need more than one value per channel", fn);
+    return 0;
+}
+
+} // namespace aq
+
+extern "C" {
+
+size_t aq_bn_workspace_bytes(int N, int C, int HW)
+{
+    if (N < 1 || C < 1 || HW < 1) return 0;
+    const aq::BnGeom g = aq::bn_geom(N, C, HW);
+    return (size_t)C * g.S * sizeof(float2);
+}
+
+int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                   long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
+                   float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace aq;
+    const bool eval = flags & AQ_BN_EVAL, relu = flags & AQ_BN_RELU;
+    if (int rc = check_dims("aq_bn_relu_fwd", N, C, HW, !eval)) return rc;
+    AQ_REQUIRE(x && gamma && beta && y, -EFAULT, "aq_bn_relu_fwd: NULL pointer");
+    AQ_REQUIRE(eps >= 0.0f, -EINVAL, "aq_bn_relu_fwd: negative eps");
+    AQ_REQUIRE((flags & ~(AQ_BN_RELU | AQ_BN_EVAL)) == 0, -EINVAL, "aq_bn_relu_fwd: unknown flags 0x%x", flags);
+    const BnGeom g = bn_geom(N, C, HW);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(y);
+    if (eval) {
+        AQ_REQUIRE(running_mean && running_var, -EFAULT, "aq_bn_relu_fwd: evaluation mode needs the running statistics");
+    } else {
+        AQ_REQUIRE(save_mean && save_rstd, -EFAULT, "aq_bn_relu_fwd: NULL save_mean / save_rstd");
+        AQ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), -EINVAL, "aq_bn_relu_fwd: running_mean and running_var go together");
+        AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_fwd: workspace of %zu bytes needed, %zu given",
+                   (size_t)C * g.S * sizeof(float2), workspace_bytes);
+        if (vec) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(g.S, C), dim3(BN_T), 0, st, x, static_cast<float2 *>(workspace), g);
+        else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.S, C), dim3(BN_T), 0, st, x, static_cast<float2 *>(workspace), g);
+    }
+    BnApplyArgs a{x, y, static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
+                  save_mean, save_rstd, eps, momentum, eval ? 1 : 0};
+    const dim3 grid(g.S2, C);
+    if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true>), grid, dim3(BN_T), 0, st, a, g);
+    else if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, false>), grid, dim3(BN_T), 0, st, a, g);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, dim3(BN_T), 0, st, a, g);
+    else hipLaunchKernelGGL((bn_apply_kernel<1, false>), grid, dim3(BN_T), 0, st, a, g);
+    return check_launch("aq_bn_relu_fwd");
+}
+
+int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
+                   const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma,
+                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_dims("aq_bn_relu_bwd", N, C, HW, true)) return rc;
+    AQ_REQUIRE(dy && x && gamma && beta && save_mean && save_rstd && dx, -EFAULT, "aq_bn_relu_bwd: NULL pointer");
+    AQ_REQUIRE((flags & ~AQ_BN_RELU) == 0, -EINVAL, "aq_bn_relu_bwd: unsupported flags 0x%x (batch-statistics mode only)", flags);
+    const BnGeom g = bn_geom(N, C, HW);
+    AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_bwd: workspace of %zu bytes needed, %zu given",
+               (size_t)C * g.S * sizeof(float2), workspace_bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool relu = flags & AQ_BN_RELU;
+    const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && (!res || aligned16(res));
+    BnBwdArgs a{dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta};
+    const dim3 g1(g.S, C), g2(g.S2, C);
+#define AQ_BN_BWD(V, R)                                                                                        \
+    {                                                                                                          \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, R>), g1, dim3(BN_T), 0, st, a, g);                         \
+        if (res) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R, true>), g2, dim3(BN_T), 0, st, a, g);           \
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R, false>), g2, dim3(BN_T), 0, st, a, g);              \
+    }
+    if (vec && relu) AQ_BN_BWD(4, true)
+    else if (vec) AQ_BN_BWD(4, false)
+    else if (relu) AQ_BN_BWD(1, true)
+    else AQ_BN_BWD(1, false)
+#undef AQ_BN_BWD
+    return check_launch("aq_bn_relu_bwd");
+}
+
+} // extern "C"

@@ -37,6 +37,7 @@ struct ConvArgs {
     const uint8_t *idx;  // codes, same shape as W (MODE_FWD_CODES)
     const float *q;      // levels (MODE_FWD_CODES)
     float *out;
+    const float *res;    // optional tensor added to the output (the block's shortcut), same shape as out
     int L;
     int N, Cin, Cout;    // conv definition
     int M, KC, K;        // GEMM: output channels, input channels, 9*KC
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ch = m0 + 16 * m + 4 * kq + r;
-                if (ch < a.M) a.out[(((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox] = acc[m][nt][r];
+                if (ch < a.M) {
+                    const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
+                    a.out[o] = a.res ? acc[m][nt][r] + a.res[o] : acc[m][nt][r];
+                }
             }
         }
 }
@@ -489,7 +493,10 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ch = m0 + 16 * m + 4 * kq + r;
-                    if (ch < a.M) a.out[(((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox] = acc[m][nt][r];
+                    if (ch < a.M) {
+                        const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
+                        a.out[o] = a.res ? acc[m][nt][r] + a.res[o] : acc[m][nt][r];
+                    }
                 }
             }
         __syncthreads();  // every wavefront is done with this tile's LDS image
@@ -873,14 +880,14 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
     return check_launch(who);
 }
 
-static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, const float *q, int L, float *y, int N, int Cin, int H,
-                           int Wd, int Cout, int ks, int stride, int pad, hipStream_t st, const char *who)
+static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, const float *q, int L, const float *res, float *y, int N, int Cin,
+                           int H, int Wd, int Cout, int ks, int stride, int pad, hipStream_t st, const char *who)
 {
     if (int rc = check_conv(who, N, Cin, H, Wd, Cout, ks, stride, pad)) return rc;
     if (N == 0) return 0;
     AQ_REQUIRE(x && y && (W || (idx && q)), -EFAULT, "%s: NULL pointer", who);
     ConvArgs a = {};
-    a.in = x; a.W = W; a.idx = idx; a.q = q; a.L = L; a.out = y;
+    a.in = x; a.W = W; a.idx = idx; a.q = q; a.L = L; a.out = y; a.res = res;
     a.N = N; a.Cin = Cin; a.Cout = Cout;
     a.M = Cout; a.KC = Cin; a.K = Cin * 9;
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
@@ -894,7 +901,15 @@ extern "C" {
 
 int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
 {
-    return aq::conv_fwd_common(x, W, nullptr, nullptr, 0, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd");
+    return aq::conv_fwd_common(x, W, nullptr, nullptr, 0, nullptr, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd");
+}
+
+int aq_conv_fwd_add(const float *x, const float *W, const float *res, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
+                    int pad, void *stream)
+{
+    AQ_REQUIRE(res || N == 0, -EFAULT, "aq_conv_fwd_add: NULL res");
+    return aq::conv_fwd_common(x, W, nullptr, nullptr, 0, res, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream),
+                               "aq_conv_fwd_add");
 }
 
 int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize,
@@ -902,7 +917,7 @@ int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L,
 {
     AQ_REQUIRE(L >= 1 && L <= AQ_MAX_LEVELS, -EINVAL, "aq_conv_fwd_codes: L=%d outside 1..%d", L, AQ_MAX_LEVELS);
     AQ_REQUIRE(idx && q, -EFAULT, "aq_conv_fwd_codes: NULL codes / levels");
-    return aq::conv_fwd_common(x, nullptr, idx, q, L, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd_codes");
+    return aq::conv_fwd_common(x, nullptr, idx, q, L, nullptr, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd_codes");
 }
 
 int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)

@@ -93,12 +93,14 @@ class _SynthAll(torch.autograd.Function):
 
 
 class _Conv3x3(torch.autograd.Function):
+    """y = conv3x3(x, W) [+ res]; the gradient of res is dy itself."""
+
     @staticmethod
-    def forward(ctx, x, W, stride, dW_slot):
+    def forward(ctx, x, W, stride, dW_slot, res):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
         ctx.stride, ctx.dW_slot = stride, dW_slot
-        return ops.conv_forward(x, W, stride)
+        return ops.conv_forward(x, W, stride, res.contiguous() if res is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -106,7 +108,51 @@ class _Conv3x3(torch.autograd.Function):
         dy = dy.contiguous()
         dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
         dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot) if ctx.needs_input_grad[1] else None
-        return dx, dW, None, None
+        return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None)
+
+
+class _BnRelu(torch.autograd.Function):
+    """z = relu(batch_norm(x)) with batch statistics.  With split=True the function also hands x
+    through as a second output, so that the gradient arriving over a block's shortcut is added inside
+    the backward kernel instead of by a separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu, split):
+        x = x.contiguous()
+        z, mean, rstd = ops.bn_relu_forward(x, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                            bn.momentum, relu=relu)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.relu = relu
+        return (z, x.view_as(x)) if split else z
+
+    @staticmethod
+    def backward(ctx, dz, dres=None):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if dz is None:
+            dz = torch.zeros_like(x)
+        dx, dg, db = ops.bn_relu_backward(dz.contiguous(), x, gamma, beta, mean, rstd, res=dres.contiguous() if dres is not None else None,
+                                          relu=ctx.relu)
+        return dx, dg, db, None, None, None
+
+
+def bn_relu(bn, x, relu=True, split=False):
+    """relu(bn(x)) for an nn.BatchNorm2d module `bn` on the HIP kernels (adp_qtz_fan.py:674-675, 690,
+    726, 730).  split=True returns (z, x') where x' is x for the shortcut path."""
+    if not x.is_cuda:
+        raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
+    if bn.weight is None or (bn.training and bn.momentum is None) or x.dtype != torch.float32:
+        z = bn(x)  # module configurations the reference does not use: stock operator
+        z = F.relu(z) if relu else z
+        return (z, x) if split else z
+    if bn.training or bn.running_mean is None:
+        return _BnRelu.apply(x, bn.weight, bn.bias, bn, relu, split)
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        z = bn(x)  # gradients through running-statistics normalisation: stock operator
+        z = F.relu(z) if relu else z
+    else:
+        z = ops.bn_relu_forward(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps, 0.0, relu=relu,
+                                use_running_stats=True)[0]
+    return (z, x) if split else z
 
 
 class _LinearIO(torch.autograd.Function):
@@ -195,15 +241,17 @@ class QConv2d(_QuantBase):
         self.ksize, self.stride, self.padding = ksize, stride, padding
         self._init_levels(config, config.num_level_conv, in_channel * ksize * ksize, s)
 
-    def forward(self, x):
+    def forward(self, x, res=None):
+        """res: optional tensor added to the output inside the convolution kernel (the shortcut)."""
         assert len(x.shape) == 4
         if self.ksize != 3 or self.padding != 1 or self.stride not in (1, 2):
             raise NotImplementedError("the HIP convolution implements ksize=3, padding=1, stride 1|2 "
                                       "(got ksize=%d padding=%d stride=%d)" % (self.ksize, self.padding, self.stride))
         w, slot = self.synthesize()
         if self.mode == "train":
-            return _Conv3x3.apply(x, w, self.stride, slot)
-        return ops.conv_forward_codes(x.contiguous(), w["idx"][0], self.q_level.detach(), self.stride)
+            return _Conv3x3.apply(x, w, self.stride, slot, res)
+        y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], self.q_level.detach(), self.stride)
+        return y if res is None else y + res
 
 
 class QLinear(_QuantBase):
@@ -231,6 +279,18 @@ class _Block(nn.Module):
         if not increase_dim:
             return nn.Identity()
         return nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0, in_channel // 2, in_channel // 2)))
+
+    def _residual_forward(self, x):
+        """adp_qtz_fan.py:673-678.  bn1 hands x through for the shortcut so that the shortcut's gradient
+        is added inside bn1's backward kernel; the shortcut itself is added inside conv2's kernel."""
+        out, xs = bn_relu(self.bn1, x, split=True)
+        out = bn_relu(self.bn2, self.conv1(out))
+        return self.conv2(out, res=self.shortcut(xs))
+
+    def _preresidual_forward(self, x):
+        """adp_qtz_fan.py:689-693"""
+        out = bn_relu(self.bn2, self.conv1(x))
+        return self.conv2(out, res=x)
 
 
 class QResNet(nn.Module):
@@ -277,18 +337,18 @@ class QResNet(nn.Module):
         an ordinary dense parameter, the arithmetic runs on the same MFMA convolution kernels."""
         c0 = self.conv0
         if c0.kernel_size == (3, 3) and c0.padding == (1, 1) and c0.stride in ((1, 1), (2, 2)) and c0.bias is None:
-            return _Conv3x3.apply(x, c0.weight, c0.stride[0], None)
+            return _Conv3x3.apply(x, c0.weight, c0.stride[0], None, None)
         return c0(x)
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._synthesize_all()
-        out = F.relu(self.bn0(self.stem(x)))
+        out = bn_relu(self.bn0, self.stem(x))
         out = self.layer1(out)
         out = self.layer2(out)
         out = self.layer3(out)
-        out = F.relu(self.bnlast(out))
+        out = bn_relu(self.bnlast, out)
         out = self.ap(out)
         out = out.view(out.size(0), -1)
         out = self.linear(out)

@@ -125,12 +125,19 @@ def conv_out_shape(x_shape, Cout, stride):
     return (N, Cout, (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1)
 
 
-def conv_forward(x, W, stride=1):
-    """y = conv2d(x, W, stride, padding=1), W (Cout, Cin, 3, 3)  (adp_qtz_fan.py:574-601)."""
+def conv_forward(x, W, stride=1, res=None):
+    """y = conv2d(x, W, stride, padding=1) [+ res], W (Cout, Cin, 3, 3)  (adp_qtz_fan.py:574-601;
+    res: the shortcut added after conv2, :676-677)."""
     if W.dim() != 4 or W.shape[2] != 3 or W.shape[3] != 3 or x.dim() != 4 or W.shape[1] != x.shape[1]:
         raise ValueError("conv_forward: x %s / W %s: need NCHW input and (Cout, Cin, 3, 3) weights" % (tuple(x.shape), tuple(W.shape)))
     y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().aq_conv_fwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(y), *_conv_dims(x.shape, W.shape[0], stride), _lib.stream()))
+    dims = _conv_dims(x.shape, W.shape[0], stride)
+    if res is None:
+        _lib.check(_lib.lib().aq_conv_fwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(y), *dims, _lib.stream()))
+    else:
+        if tuple(res.shape) != tuple(y.shape):
+            raise ValueError("conv_forward: res %s does not match the output %s" % (tuple(res.shape), tuple(y.shape)))
+        _lib.check(_lib.lib().aq_conv_fwd_add(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(y), *dims, _lib.stream()))
     return y
 
 
@@ -186,3 +193,52 @@ def linear_backward(x, W, dy, need_dx=True):
     _lib.check(_lib.lib().aq_linear_bwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(dy, name="dy"), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db),
                                         N, In, Out, _lib.stream()))
     return dx, dW, db
+
+
+# ------------------------------------------------------------------------- batch norm (+ ReLU)
+
+def _bn_dims(x):
+    if x.dim() < 2:
+        raise ValueError("batch norm input needs at least 2 dimensions, got %s" % (tuple(x.shape),))
+    N, Cn = int(x.shape[0]), int(x.shape[1])
+    return N, Cn, int(x.numel() // max(N * Cn, 1))
+
+
+def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1,
+                    relu=True, use_running_stats=False):
+    """y = [relu](batch_norm(x)) over (N, H, W) of an NCHW tensor (adp_qtz_fan.py:674-675, 690, 726, 730).
+    Batch-statistics mode returns (y, save_mean, save_rstd) and updates the running statistics in
+    place like nn.BatchNorm2d in training mode; use_running_stats=True normalises with them instead."""
+    N, Cn, HW = _bn_dims(x)
+    y = torch.empty_like(x)
+    flags = (_lib.BN_RELU if relu else 0) | (_lib.BN_EVAL if use_running_stats else 0)
+    mean = rstd = ws = None
+    nbytes = 0
+    if not use_running_stats:
+        mean = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_bn_relu_fwd(
+        _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
+        _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), N, Cn, HW,
+        float(eps), float(momentum), flags, _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), ws.data_ptr() if ws is not None else None, nbytes,
+        _lib.stream()))
+    return y, mean, rstd
+
+
+def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True):
+    """-> (dx [+ res], dgamma, dbeta) of bn_relu_forward in batch-statistics mode."""
+    N, Cn, HW = _bn_dims(x)
+    if dy.shape != x.shape or (res is not None and res.shape != x.shape):
+        raise ValueError("bn_relu_backward: dy / res must have the shape of x %s" % (tuple(x.shape),))
+    dx = torch.empty_like(x)
+    dg = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    db = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_bn_relu_bwd(
+        _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
+        _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(res, name="res"), N, Cn, HW,
+        _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), ws.data_ptr(), nbytes, _lib.stream()))
+    return dx, dg, db

@@ -392,10 +392,55 @@ def gen_train(torch):
     np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
 
 
+def gen_block(torch):
+    """Whole residual blocks of the reference (BatchNorm in training mode + ReLU + quantized convs +
+    shortcut): parameters, input, upstream gradient -> output, input gradient, parameter gradients,
+    running statistics after the forward pass."""
+    mod = load_ref("adp_qtz_fan.py")
+    mod.beta = 2
+    rs = np.random.RandomState(2024)
+    out = {}
+    cases = [("residual", 16, False, 8, 4), ("residual", 16, True, 8, 3), ("preresidual", 16, False, 6, 2),
+             ("residual", 32, False, 5, 2)]
+    L = 4
+    for i, (kind, cin, inc, H, N) in enumerate(cases):
+        c = cfg(L=L)
+        blk = mod.Residual(c, cin, inc) if kind == "residual" else mod.PreResidual(c, cin)
+        blk.train()
+        k = "b%02d_" % i
+        with torch.no_grad():
+            for name, p in blk.named_parameters():
+                n = p.numel()
+                if name.endswith("p_c"):
+                    a = rs.random_sample(n)
+                elif name.endswith("q_level"):
+                    a = rs.uniform(-0.3, 0.3, n)
+                elif name.endswith("weight"):
+                    a = 1.0 + 0.2 * rs.standard_normal(n)
+                else:
+                    a = 0.2 * rs.standard_normal(n)
+                p.copy_(torch.from_numpy(a.astype(np.float32)).reshape(p.shape))
+                out[k + "param_" + name] = f32(p.detach().numpy())
+        x = torch.from_numpy((rs.standard_normal((N, cin, H, H)) * 1.5 + 0.3).astype(np.float32)).requires_grad_(True)
+        y = blk.forward(x * 1.0)  # (the block adds the shortcut in place: keep the leaf out of it)
+        g = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * g).sum().backward()
+        out[k + "kind"] = np.array(kind); out[k + "shape"] = np.array([cin, int(inc), H, N], np.int64)
+        out[k + "x"] = f32(x.detach().numpy()); out[k + "g"] = f32(g.numpy())
+        out[k + "y"] = f32(y.detach().numpy()); out[k + "dx"] = f32(x.grad.numpy())
+        for name, p in blk.named_parameters():
+            out[k + "grad_" + name] = f32(p.grad.numpy())
+        for name, b in blk.named_buffers():
+            out[k + "buf_" + name] = np.asarray(b.detach().numpy())
+    out["ncase"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "block.npz"), **out)
+    print("block.npz: %d cases" % len(cases))
+
+
 def main():
     import torch
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train"]
+    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block"]
     for w in which:
         globals()["gen_" + w](torch)
 

@@ -262,3 +262,101 @@ def test_linear_vs_oracle_and_fixture(golden):
         assert np.abs(dx.cpu().numpy() - g[k + "dx"]).max() <= 1e-5 * np.abs(g[k + "dx"]).max()
         assert np.abs(dW.cpu().numpy() - g[k + "dW"]).max() <= 1e-5 * np.abs(g[k + "dW"]).max()
         assert np.abs(db.cpu().numpy() - g[k + "dbias"]).max() <= 1e-5 * np.abs(g[k + "dbias"]).max()
+
+
+# ------------------------------------------------------------------------- batch norm (+ ReLU)
+# fp32 reductions in a fixed tree order against the oracle's double accumulation: 1e-5 of the tensor's
+# scale for y / dx, rel 2e-5 for per-channel sums; elements whose pre-activation is within 1e-6 of zero
+# may fall on either side of the ReLU and are excluded from the backward comparison.
+
+BN_SHAPES = [(128, 16, 32, 32), (128, 32, 16, 16), (128, 64, 8, 8), (8, 16, 32, 32), (3, 5, 7, 3), (2, 1, 1, 1), (5, 7, 1, 1),
+             (130, 3, 5, 5), (1, 4, 50, 50), (2, 2, 64, 64)]
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shape", BN_SHAPES)
+def test_bn_relu_forward_backward_vs_oracle(shape, relu):
+    rs = np.random.RandomState(sum(shape) + int(relu))
+    N, Cn = shape[0], shape[1]
+    x = (rs.standard_normal(shape) * rs.uniform(0.5, 3.0, (1, Cn, 1, 1)) + rs.uniform(-2, 2, (1, Cn, 1, 1))).astype(np.float32)
+    gamma = (1.0 + 0.3 * rs.standard_normal(Cn)).astype(np.float32)
+    beta = (0.3 * rs.standard_normal(Cn)).astype(np.float32)
+    dy = rs.standard_normal(shape).astype(np.float32)
+    res = rs.standard_normal(shape).astype(np.float32)
+    rm0, rv0 = rs.standard_normal(Cn).astype(np.float32), rs.uniform(0.5, 2, Cn).astype(np.float32)
+    rm, rv, nbt = cu(rm0), cu(rv0), torch.tensor(41, device=DEV, dtype=torch.int64)
+    xd, gd, bd = cu(x), cu(gamma), cu(beta)
+    y, mean, rstd = ops.bn_relu_forward(xd, gd, bd, rm, rv, nbt, 1e-5, 0.1, relu=relu)
+    yo, mo, ro, vo = O.bn_relu_fwd(x, gamma, beta, 1e-5, relu)
+    assert np.abs(y.cpu().numpy() - yo).max() <= 1e-5 * max(1.0, np.abs(yo).max())
+    assert np.allclose(mean.cpu().numpy(), mo, rtol=1e-5, atol=1e-6)
+    assert np.allclose(rstd.cpu().numpy(), ro, rtol=2e-5)
+    assert np.allclose(rm.cpu().numpy(), 0.9 * rm0 + 0.1 * mo, rtol=1e-5, atol=1e-6)
+    assert np.allclose(rv.cpu().numpy(), 0.9 * rv0 + 0.1 * vo, rtol=2e-5)
+    assert int(nbt) == 42
+    # evaluation mode: running statistics, nothing updated
+    ye = ops.bn_relu_forward(xd, gd, bd, rm, rv, None, 1e-5, 0.0, relu=relu, use_running_stats=True)[0]
+    t = (x - rm.cpu().numpy().reshape(1, -1, 1, 1)) / np.sqrt(rv.cpu().numpy().reshape(1, -1, 1, 1) + 1e-5) * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
+    t = np.maximum(t, 0) if relu else t
+    assert np.abs(ye.cpu().numpy() - t).max() <= 1e-5 * max(1.0, np.abs(t).max())
+    assert int(nbt) == 42
+    # backward, with and without the shortcut gradient
+    for r in (None, res):
+        dx, dg, db = ops.bn_relu_backward(cu(dy), xd, gd, bd, mean, rstd, res=cu(r) if r is not None else None, relu=relu)
+        dxo, dgo, dbo = O.bn_relu_bwd(dy, x, gamma, beta, r, 1e-5, relu)
+        pre = (x - mo.reshape(1, -1, 1, 1)) * ro.reshape(1, -1, 1, 1) * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
+        near = (np.abs(pre) < 1e-6) & relu
+        if near.any():
+            continue  # a borderline ReLU decision changes the channel sums: skip this (rare) draw
+        scale = max(1.0, np.abs(dxo).max())
+        assert np.abs(dx.cpu().numpy() - dxo).max() <= 2e-5 * scale
+        n_per = x.size // Cn
+        assert np.abs(dg.cpu().numpy() - dgo).max() <= 2e-5 * max(1.0, np.abs(dgo).max(), np.sqrt(n_per))
+        assert np.abs(db.cpu().numpy() - dbo).max() <= 2e-5 * max(1.0, np.abs(dbo).max(), np.sqrt(n_per))
+
+
+def test_bn_large_mean_does_not_cancel():
+    """mean >> std: the two-pass slice statistics keep the variance accurate."""
+    rs = np.random.RandomState(5)
+    x = (1000.0 + 0.01 * rs.standard_normal((64, 8, 16, 16))).astype(np.float32)
+    g, b = np.ones(8, np.float32), np.zeros(8, np.float32)
+    y, mean, rstd = ops.bn_relu_forward(cu(x), cu(g), cu(b), None, None, None, 1e-5, 0.1, relu=False)
+    yo, mo, ro, _ = O.bn_relu_fwd(x, g, b, 1e-5, False)
+    assert np.allclose(rstd.cpu().numpy(), ro, rtol=1e-3)
+    assert np.abs(y.cpu().numpy() - yo).max() <= 2e-2  # inputs carry 6e-5 absolute rounding, amplified by rstd ~ 100
+
+
+def test_bn_matches_torch_batch_norm_and_is_deterministic():
+    torch.manual_seed(3)
+    x = torch.randn(128, 32, 16, 16, device=DEV) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(32).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    rm, rv, nbt = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+    y1, m1, r1 = ops.bn_relu_forward(x, bn.weight.detach(), bn.bias.detach(), rm, rv, nbt, bn.eps, bn.momentum)
+    y2, m2, r2 = ops.bn_relu_forward(x, bn.weight.detach(), bn.bias.detach(), rm.clone(), rv.clone(), nbt.clone(), bn.eps, bn.momentum)
+    assert torch.equal(y1, y2) and torch.equal(m1, m2) and torch.equal(r1, r2)
+    yt = torch.relu(bn(x))
+    assert (y1 - yt).abs().max().item() <= 1e-5 * yt.abs().max().item()
+    assert torch.allclose(rm, bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(rv, bn.running_var, rtol=1e-5)
+    assert int(nbt) == int(bn.num_batches_tracked) == 1
+
+
+def test_conv_forward_with_shortcut_add():
+    rs = np.random.RandomState(8)
+    for (N, cin, cout, s, H) in [(4, 16, 16, 1, 32), (3, 16, 32, 2, 16), (2, 5, 7, 1, 9)]:
+        x, W = cu(rs.standard_normal((N, cin, H, H))), cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+        y0 = ops.conv_forward(x, W, s)
+        res = cu(rs.standard_normal(tuple(y0.shape)))
+        y1 = ops.conv_forward(x, W, s, res=res)
+        assert torch.equal(y1, y0 + res)  # one fp32 addition after the same accumulation
+
+
+def test_bn_argument_errors():
+    x = torch.zeros(1, 3, 1, 1, device=DEV)
+    g = torch.ones(3, device=DEV)
+    with pytest.raises(RuntimeError, match="more than one value"):
+        ops.bn_relu_forward(x, g, g, None, None, None)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ops.bn_relu_forward(torch.zeros(2, 3, 2, 2), g, g, None, None, None)

@@ -181,3 +181,65 @@ def test_fused_step_matches_reference_curve(golden, variant, graph):
     assert np.abs(np.array(regs) - g[k + "reg"]).max() <= 1e-4 * g[k + "reg"].max()
     sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
     assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+
+
+def test_residual_blocks_match_reference_fixture(golden):
+    """Whole blocks (fused BatchNorm+ReLU kernels, quantized convolutions, shortcut added inside the
+    convolution kernel, shortcut gradient added inside the BatchNorm backward kernel) against the
+    reference's blocks.  Tolerance 3e-5 of each tensor's scale (fp32 both sides, other summation order)."""
+    g = golden("block")
+    fan.beta = 2
+    try:
+        for c in range(int(g["ncase"])):
+            k = "b%02d_" % c
+            kind, (cin, inc, H, N) = str(g[k + "kind"]), [int(v) for v in g[k + "shape"]]
+            conf = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=4, num_level_fc=4, l2_reg=5e-4)
+            blk = fan.Residual(conf, cin, bool(inc)) if kind == "residual" else fan.PreResidual(conf, cin)
+            with torch.no_grad():
+                for name, p in blk.named_parameters():
+                    p.copy_(torch.from_numpy(g[k + "param_" + name]))
+            blk = blk.cuda().train()
+            x = torch.from_numpy(g[k + "x"]).cuda().requires_grad_(True)
+            y = blk(x)
+            (y * torch.from_numpy(g[k + "g"]).cuda()).sum().backward()
+
+            def near(a, ref, what):
+                ref = np.asarray(ref)
+                err = np.abs(a.detach().cpu().numpy() - ref).max()
+                assert err <= 3e-5 * max(np.abs(ref).max(), 1e-3), (c, kind, what, err)
+            near(y, g[k + "y"], "y")
+            near(x.grad, g[k + "dx"], "dx")
+            for name, p in blk.named_parameters():
+                near(p.grad, g[k + "grad_" + name], name)
+            for name, b in blk.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    assert int(b) == int(g[k + "buf_" + name])
+                else:
+                    near(b, g[k + "buf_" + name], name)
+    finally:
+        fan.beta = 1
+
+
+def test_eval_mode_batchnorm_uses_running_statistics():
+    conf = cfg()
+    torch.manual_seed(0)
+    m = fan.ResNet(conf, 3).cuda()
+    x = torch.randn(4, 3, 32, 32, device="cuda")
+    m.train()
+    for _ in range(2):
+        m(x)
+    m.eval()
+    before = [b.clone() for b in m.buffers()]
+    with torch.no_grad():
+        y1 = m(x)
+    assert all(torch.equal(a, b) for a, b in zip(before, m.buffers()))
+    # stock operators for the normalisation give the same logits
+    import quantized_cnn_amd.layers as layers
+    own = layers.bn_relu
+    layers.bn_relu = lambda bn, t, relu=True, split=False: ((torch.relu(bn(t)), t) if split else torch.relu(bn(t)))
+    try:
+        with torch.no_grad():
+            y2 = m(x)
+    finally:
+        layers.bn_relu = own
+    assert (y1 - y2).abs().max().item() <= 1e-4 * max(1.0, y2.abs().max().item())

@@ -207,3 +207,58 @@ def test_torch_port_training_curve_matches_reference(golden, variant, impl):
             assert np.abs(logits.numpy() - g[k + "logits0"]).max() <= 2e-5 * np.abs(g[k + "logits0"]).max()
             assert abs(reg - g[k + "reg"][0]) <= 1e-5 * g[k + "reg"][0]
     assert np.abs(np.array(losses) - g[k + "loss"]).max() <= 1e-4 * g[k + "loss"].max()
+
+
+def _block_params(g, k):
+    P = {n[len(k + "param_"):]: g[n] for n in g.files if n.startswith(k + "param_")}
+    G = {n[len(k + "grad_"):]: g[n] for n in g.files if n.startswith(k + "grad_")}
+    return P, G
+
+
+def test_block_with_batchnorm_matches_reference(golden):
+    """Residual / PreResidual blocks of the reference (BatchNorm in training mode, ReLU, two quantized
+    convolutions, identity shortcut) rebuilt from the oracle's pieces.  Tolerance 2e-5 of the
+    tensor's scale (fp32 reference vs double-accumulating oracle)."""
+    g = golden("block")
+    done = 0
+    for c in _cases(g):
+        k = "b%02d_" % c
+        kind, (cin, inc, H, N) = str(g[k + "kind"]), [int(v) for v in g[k + "shape"]]
+        if inc:
+            continue  # pooled + zero-padded shortcut: covered by the GPU model tests
+        P, G = _block_params(g, k)
+        x, gy = g[k + "x"], g[k + "g"]
+        W1 = O.synth_fwd(P["conv1.p_c"], P["conv1.q_level"], 2.0)["W"]
+        W2 = O.synth_fwd(P["conv2.p_c"], P["conv2.q_level"], 2.0)["W"]
+        if kind == "residual":
+            z1 = O.bn_relu_fwd(x, P["bn1.weight"], P["bn1.bias"])[0]
+        else:
+            z1 = x
+        c1 = O.conv_fwd(z1, W1, 1)
+        z2, mean2, _, var2 = O.bn_relu_fwd(c1, P["bn2.weight"], P["bn2.bias"])
+        y = O.conv_fwd(z2, W2, 1) + x
+        tol = lambda ref: 2e-5 * np.abs(ref).max()
+        assert np.abs(y - g[k + "y"]).max() <= tol(g[k + "y"])
+        # running statistics after one training-mode forward (momentum 0.1, unbiased variance)
+        assert np.allclose(0.1 * mean2, g[k + "buf_bn2.running_mean"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(0.9 + 0.1 * var2, g[k + "buf_bn2.running_var"], rtol=1e-5)
+        assert int(g[k + "buf_bn2.num_batches_tracked"]) == 1
+        # backward
+        dz2 = O.conv_dgrad(gy, W2, z2.shape, 1)
+        dc1, dg2, db2 = O.bn_relu_bwd(dz2, c1, P["bn2.weight"], P["bn2.bias"])
+        assert np.abs(dg2 - G["bn2.weight"]).max() <= tol(G["bn2.weight"])
+        assert np.abs(db2 - G["bn2.bias"]).max() <= tol(G["bn2.bias"])
+        dz1 = O.conv_dgrad(dc1, W1, z1.shape, 1)
+        if kind == "residual":
+            dx, dg1, db1 = O.bn_relu_bwd(dz1, x, P["bn1.weight"], P["bn1.bias"], res=gy)
+            assert np.abs(dg1 - G["bn1.weight"]).max() <= tol(G["bn1.weight"])
+            assert np.abs(db1 - G["bn1.bias"]).max() <= tol(G["bn1.bias"])
+        else:
+            dx = dz1 + gy
+        assert np.abs(dx - g[k + "dx"]).max() <= tol(g[k + "dx"])
+        dW1 = O.conv_wgrad(z1, dc1, 3, 1)
+        dp1, dq1 = O.synth_bwd(P["conv1.p_c"], P["conv1.q_level"], 2.0, dW1)
+        assert np.abs(dp1 - G["conv1.p_c"]).max() <= 5e-5 * np.abs(G["conv1.p_c"]).max()
+        assert np.abs(dq1 - G["conv1.q_level"]).max() <= 5e-5 * np.abs(G["conv1.q_level"]).max()
+        done += 1
+    assert done >= 3
