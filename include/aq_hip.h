@@ -125,6 +125,14 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
                    size_t workspace_bytes, void *stream);
 size_t aq_bn_workspace_bytes(int N, int C, int HW);
 
+/* Shortcut of the dimension-increasing blocks, nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0,
+ * C/2, C/2))) (adp_qtz_fan.py:669-671): y[N, pad_front+C+pad_back, H/2, W/2] = 2x2 average of x[N, C, H, W]
+ * in channels [pad_front, pad_front+C), zero elsewhere; and its gradient dx[N, C, H, W]. */
+int aq_shortcut_fwd(const float *x, float *y, int N, int C, int H, int Wd, int pad_front, int pad_back,
+                    void *stream);
+int aq_shortcut_bwd(const float *dy, float *dx, int N, int C, int H, int Wd, int pad_front, int pad_back,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ EXPORTS = (
     "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
+    "aq_shortcut_fwd", "aq_shortcut_bwd",
 )
 
 
@@ -61,10 +62,12 @@ def lib():
         L.aq_linear_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.aq_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, f, C.c_uint, vp, vp, vp, vp, sz, vp]
         L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, vp]
+        L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+        L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_bn_workspace_bytes.argtypes = [i, i, i]
         L.aq_bn_workspace_bytes.restype = sz
         for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",
-                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd"):
+                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_shortcut_fwd", "aq_shortcut_bwd"):
             getattr(L, name).restype = i
         if L.aq_abi_version() != ABI_VERSION:
             raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))

@@ -135,6 +135,20 @@ class _BnRelu(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
+class _Shortcut(torch.autograd.Function):
+    """AvgPool2d(2) + ZeroPad2d over channels (adp_qtz_fan.py:669-671) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, front, back):
+        x = x.contiguous()
+        ctx.shape, ctx.pads = tuple(x.shape), (front, back)
+        return ops.shortcut_forward(x, front, back)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.shortcut_backward(dy.contiguous(), ctx.shape, *ctx.pads), None, None
+
+
 def bn_relu(bn, x, relu=True, split=False):
     """relu(bn(x)) for an nn.BatchNorm2d module `bn` on the HIP kernels (adp_qtz_fan.py:674-675, 690,
     726, 730).  split=True returns (z, x') where x' is x for the shortcut path."""
@@ -278,14 +292,22 @@ class _Block(nn.Module):
     def _shortcut(self, in_channel, increase_dim):
         if not increase_dim:
             return nn.Identity()
+        self._pad = in_channel // 2
         return nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0, in_channel // 2, in_channel // 2)))
+
+    def _apply_shortcut(self, x):
+        if isinstance(self.shortcut, nn.Identity):
+            return x
+        if getattr(self, "_pad", None) is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+            return _Shortcut.apply(x, self._pad, self._pad)
+        return self.shortcut(x)
 
     def _residual_forward(self, x):
         """adp_qtz_fan.py:673-678.  bn1 hands x through for the shortcut so that the shortcut's gradient
         is added inside bn1's backward kernel; the shortcut itself is added inside conv2's kernel."""
         out, xs = bn_relu(self.bn1, x, split=True)
         out = bn_relu(self.bn2, self.conv1(out))
-        return self.conv2(out, res=self.shortcut(xs))
+        return self.conv2(out, res=self._apply_shortcut(xs))
 
     def _preresidual_forward(self, x):
         """adp_qtz_fan.py:689-693"""
@@ -344,6 +366,10 @@ class QResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._synthesize_all()
+        return self.forward_body(x)
+
+    def forward_body(self, x):
+        """adp_qtz_fan.py:725-734 with the weights of the quantized layers already synthesised."""
         out = bn_relu(self.bn0, self.stem(x))
         out = self.layer1(out)
         out = self.layer2(out)

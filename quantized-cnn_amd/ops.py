@@ -242,3 +242,24 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
         _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(res, name="res"), N, Cn, HW,
         _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), ws.data_ptr(), nbytes, _lib.stream()))
     return dx, dg, db
+
+
+# -------------------------------------------------------------------------------------- shortcut
+
+def shortcut_forward(x, pad_front, pad_back):
+    """AvgPool2d(2) + zero channels in front / behind (adp_qtz_fan.py:669-671)."""
+    N, Cn, H, Wd = x.shape
+    y = torch.empty((N, Cn + pad_front + pad_back, H // 2, Wd // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aq_shortcut_fwd(_lib.ptr(x, name="x"), _lib.ptr(y), int(N), int(Cn), int(H), int(Wd), int(pad_front), int(pad_back),
+                                          _lib.stream()))
+    return y
+
+
+def shortcut_backward(dy, x_shape, pad_front, pad_back):
+    N, Cn, H, Wd = x_shape
+    if tuple(dy.shape) != (N, Cn + pad_front + pad_back, H // 2, Wd // 2):
+        raise ValueError("shortcut_backward: dy %s does not match x %s" % (tuple(dy.shape), tuple(x_shape)))
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().aq_shortcut_bwd(_lib.ptr(dy, name="dy"), _lib.ptr(dx), int(N), int(Cn), int(H), int(Wd), int(pad_front), int(pad_back),
+                                          _lib.stream()))
+    return dx

@@ -190,12 +190,12 @@ def beta_schedule(config, epoch, beta, opts):
 class FusedTrainStep:
     """Same arithmetic as TrainStep, arranged for HIP graphs and data parallelism:
 
-        graph A : zero flat grads; ONE synthesis launch (W of all layers + sum W^2);
-                  forward; CE + l2_reg * sum(dense "weight"^2); backward with the synthesised W as
-                  leaves -> d loss/d W of every quantized layer lands in one flat buffer, dense
-                  gradients accumulate into views of the same buffer
+        graph A : ONE synthesis launch (W of all layers + sum W^2); forward; CrossEntropy; backward
+                  with the synthesised W as leaves -> d loss/d W of every quantized layer lands in one
+                  flat buffer; for the exchange the dense gradients are gathered behind them
         comm    : one all-reduce of that buffer (only when world_size > 1; never captured)
-        graph B : ONE synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq); 3x Adam
+        graph B : regulariser gradient of the dense "weight" tensors (one multi-tensor launch); ONE
+                  synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq); 3x Adam
 
     Both graphs are captured once per (input shape, beta, learning rates) and replayed; with
     use_graph=False the same two phases run eagerly.
@@ -231,6 +231,10 @@ class FusedTrainStep:
         self._key = None
         self.loss = self.reg = self.logits = None
 
+    @property
+    def _exchange(self):
+        return self.dp is not None and self.dp.world > 1
+
     # ---- the two phases ---------------------------------------------------------------------
     def _phase_a(self, x, y):
         from . import ops
@@ -245,24 +249,21 @@ class FusedTrainStep:
             leaves.append(w)
             l._shared = (w, slot)
         self.model._synth_cache = None
-        logits = self._forward_body(x)
-        dense_sq = torch.cat([d.reshape(-1) for d in self.dense_reg]).pow(2).sum()
+        logits = self.model.forward_body(x)
         ce = self.criterion(logits, y)
-        (ce + self.config.l2_reg * dense_sq).backward()
+        ce.backward()
         for w in leaves:
             w.grad = None
-        # dense gradients behind dW in the flat exchange buffer (one kernel)
-        torch.cat([p.grad.reshape(-1) for p in self.dense], out=self.g_flat[self.nW:])
-        self.reg = (self.config.l2_reg * (dense_sq + out["sumsq"].sum())).detach()
-        self.loss = ce.detach() + self.reg
+        if self._exchange:
+            # dense gradients behind dW in the flat exchange buffer (one kernel)
+            torch.cat([p.grad.reshape(-1) for p in self.dense], out=self.g_flat[self.nW:])
+        # the regulariser of the dense "weight" tensors enters the loss value here and the gradients in
+        # phase B (2*l2_reg*w added to the batch gradient, after the exchange: it is the same on every rank)
+        with torch.no_grad():
+            dense_sq = torch.stack(torch._foreach_norm(self.dense_reg)).pow(2).sum() if self.dense_reg else 0.0
+            self.reg = self.config.l2_reg * (dense_sq + out["sumsq"].sum())
+            self.loss = ce.detach() + self.reg
         self.logits = logits.detach()
-
-    def _forward_body(self, x):
-        m = self.model
-        out = torch.relu(m.bn0(m.stem(x)))
-        out = m.layer3(m.layer2(m.layer1(out)))
-        out = m.ap(torch.relu(m.bnlast(out)))
-        return m.linear(out.view(out.size(0), -1))
 
     def _phase_b(self):
         from . import ops
@@ -275,6 +276,8 @@ class FusedTrainStep:
                 views.append(self.g_flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             torch._foreach_copy_([p.grad for p in self.dense], views)
+        if self.dense_reg:
+            torch._foreach_add_([p.grad for p in self.dense_reg], [p.detach() for p in self.dense_reg], alpha=2.0 * float(self.config.l2_reg))
         ops.synth_backward([p.detach() for p in self.ps], [q.detach() for q in self.qs], float(self.module.beta),
                            self.slots, 0.0, need_dq=need_dq, out_dp=self.dp_out, out_dq=self.dq_out, dsumsq=self.dss)
         for p, g in zip(self.ps, self.dp_out):

@@ -360,3 +360,24 @@ def test_bn_argument_errors():
         ops.bn_relu_forward(x, g, g, None, None, None)
     with pytest.raises(RuntimeError, match="HIP device only"):
         ops.bn_relu_forward(torch.zeros(2, 3, 2, 2), g, g, None, None, None)
+
+
+@pytest.mark.parametrize("shape", [(128, 16, 32, 32), (4, 32, 16, 16), (2, 3, 7, 5), (1, 1, 2, 2)])
+def test_shortcut_pool_pad_forward_backward(shape):
+    """AvgPool2d(2) + channel zero padding: exact up to the order of the four additions (1 ulp)."""
+    rs = np.random.RandomState(sum(shape))
+    N, Cn, H, Wd = shape
+    front, back = Cn // 2, Cn - Cn // 2
+    x = rs.standard_normal(shape).astype(np.float32)
+    Ho, Wo = H // 2, Wd // 2
+    pooled = x[:, :, :2 * Ho, :2 * Wo].reshape(N, Cn, Ho, 2, Wo, 2).astype(np.float64).mean(axis=(3, 5))
+    want = np.zeros((N, Cn + front + back, Ho, Wo), np.float64)
+    want[:, front:front + Cn] = pooled
+    y = ops.shortcut_forward(cu(x), front, back)
+    assert y.shape == want.shape
+    assert np.abs(y.cpu().numpy() - want).max() <= 3e-7 * max(1.0, np.abs(want).max())
+    dy = rs.standard_normal(want.shape).astype(np.float32)
+    dx = ops.shortcut_backward(cu(dy), shape, front, back).cpu().numpy()
+    wdx = np.zeros(shape, np.float32)
+    wdx[:, :, :2 * Ho, :2 * Wo] = np.repeat(np.repeat(dy[:, front:front + Cn], 2, axis=2), 2, axis=3) * 0.25
+    assert np.array_equal(dx, wdx)
