@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 3
+#define AQ_ABI_VERSION 4
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -49,6 +49,10 @@ typedef struct aq_seg {
                                   2*dsumsq[0] to wd, so no host read-back is needed            */
     float *dp_c;        /* [rows, L] d loss / d p_c                                          */
     float *dq;          /* [L]    d loss / d q_level (NULL for frozen levels, fix.py:652)    */
+    /* state of torch.optim.Adam for p_c (aq_synth_bwd_adam only; same tensors as optimizer.state[p_c]) */
+    float *adam_m;      /* [rows, L] exp_avg                                                 */
+    float *adam_v;      /* [rows, L] exp_avg_sq                                              */
+    float *adam_step;   /* [1]    step count as fp32 (capturable Adam keeps it on the device) */
 } aq_seg;
 
 int aq_abi_version(void);
@@ -67,6 +71,17 @@ int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void 
 int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace,
                  size_t workspace_bytes, void *stream);
 
+/* aq_synth_bwd with the Adam update of p_c fused in: replaces `optimizer_prim.step()` for the p_c group
+ * (optimizer_prim = optim.Adam(p_c parameters, lr), adp_qtz_fan.py:208-209, 291; default betas / eps,
+ * no weight decay, no amsgrad).  Per layer: *adam_step += 1 (once per distinct pointer), then p_c,
+ * adam_m, adam_v are updated IN PLACE (p_c is written although declared const in aq_seg) with the
+ * gradient that aq_synth_bwd would have stored; dp_c may be NULL (gradient not stored).  dq as in
+ * aq_synth_bwd.  At most 24 layers per call.  workspace: aq_synth_workspace_bytes(segs, nseg, 2). */
+int aq_synth_bwd_adam(const aq_seg *segs, int nseg, float beta, float wd, double lr, double beta1,
+                      double beta2, double eps, unsigned flags, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* backward: 0 = aq_synth_fwd, 1 = aq_synth_bwd, 2 = aq_synth_bwd_adam */
 size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward);
 
 /* 3x3 / pad 1 / stride 1|2 convolution, NCHW fp32, no bias: MyConv2d.forward lines
@@ -92,6 +107,20 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
                   void *stream);
 size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
                                      int pad);
+/* The two stages of aq_conv_wgrad separately, so that the slab reductions of all layers of a backward
+ * pass can run as ONE launch at its end: aq_conv_wgrad_partial writes *nslab partial results
+ * ([nslab][Cout*Cin*9]) into workspace (same size as for aq_conv_wgrad; it must stay untouched until
+ * reduced); aq_conv_wgrad_reduce sums the slabs of every job in ascending order into its dW. */
+typedef struct aq_wgrad_job {
+    const float *part; /* workspace filled by aq_conv_wgrad_partial */
+    float *dW;         /* [n] */
+    int32_t n;         /* Cout*Cin*9 */
+    int32_t nslab;
+} aq_wgrad_job;
+int aq_conv_wgrad_partial(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout,
+                          int ksize, int stride, int pad, void *workspace, size_t workspace_bytes,
+                          int *nslab, void *stream);
+int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream);
 
 /* MyLinear (adp_qtz_fan.py:646-647): y[N,Out] = x[N,In] @ W[In,Out] + bias[Out]; and its gradients
  * dx[N,In], dW[In,Out], dbias[Out] (any of the three may be NULL). */

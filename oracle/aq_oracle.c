@@ -404,6 +404,21 @@ void aqo_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const 
     }
 }
 
+/* torch.optim.Adam update (defaults: no weight decay, no amsgrad) as the reference applies it to every
+ * parameter group (adp_qtz_fan.py:208-213, 291-293), for step number t (1-based), fp32 state:
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+void aqo_adam_step(float *p, const float *g, float *m, float *v, long long n, int t, double lr, double b1, double b2, double eps)
+{
+    const double bc1 = 1.0 - pow(b1, t), bc2s = sqrt(1.0 - pow(b2, t));
+    for (long long i = 0; i < n; ++i) {
+        const double mm = m[i] + (1.0 - b1) * ((double)g[i] - m[i]);
+        const double vv = b2 * v[i] + (1.0 - b2) * (double)g[i] * g[i];
+        m[i] = (float)mm;
+        v[i] = (float)vv;
+        p[i] = (float)(p[i] - lr / bc1 * ((double)m[i] / (sqrt((double)v[i]) / bc2s + eps)));
+    }
+}
+
 int aqo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -41,6 +41,8 @@ def lib():
         L.aqo_linear_bwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp]
         L.aqo_bn_relu_fwd.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, dp]
         L.aqo_bn_relu_bwd.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp]
+        L.aqo_adam_step.argtypes = [fp, fp, fp, fp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.aqo_adam_step.restype = None
         L.aqo_num_threads.restype = C.c_int
         L.aqo_set_num_threads.argtypes = [C.c_int]
         for f in ("aqo_synth_fwd", "aqo_synth_bwd", "aqo_conv_fwd", "aqo_conv_dgrad", "aqo_conv_wgrad",
@@ -195,6 +197,15 @@ def bn_relu_bwd(dy, x, gamma, beta, res=None, eps=1e-5, relu=True):
     lib().aqo_bn_relu_bwd(dyp, xp, gp, bp, rp, N, Cn, HW, float(eps), int(relu), dx.ctypes.data_as(fp), dg.ctypes.data_as(fp),
                           db.ctypes.data_as(fp))
     return dx, dg, db
+
+
+def adam_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """In-place torch.optim.Adam update of fp32 arrays p, m, v for step number t (1-based)."""
+    for a in (p, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    ga, gp = _f(g)
+    fp = C.POINTER(C.c_float)
+    lib().aqo_adam_step(p.ctypes.data_as(fp), gp, m.ctypes.data_as(fp), v.ctypes.data_as(fp), p.size, int(t), lr, b1, b2, eps)
 
 
 def levels_fix(s, num_level, liar=True):

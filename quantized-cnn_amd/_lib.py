@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -20,7 +20,7 @@ EXPORTS = (
     "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
-    "aq_shortcut_fwd", "aq_shortcut_bwd",
+    "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
 )
 
 
@@ -29,7 +29,12 @@ class AqSeg(C.Structure):
         ("p_c", C.c_void_p), ("q", C.c_void_p), ("rows", C.c_int64), ("L", C.c_int32), ("reserved", C.c_int32),
         ("W", C.c_void_p), ("idx", C.c_void_p), ("W_hard", C.c_void_p), ("sumsq", C.c_void_p),
         ("dW", C.c_void_p), ("dsumsq", C.c_void_p), ("dp_c", C.c_void_p), ("dq", C.c_void_p),
+        ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_void_p),
     ]
+
+
+class AqWgradJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("dW", C.c_void_p), ("n", C.c_int32), ("nslab", C.c_int32)]
 
 
 _lib = None
@@ -48,6 +53,8 @@ def lib():
         L.aq_last_error.restype = C.c_char_p
         L.aq_synth_fwd.argtypes = [C.POINTER(AqSeg), i, f, C.c_uint, vp, sz, vp]
         L.aq_synth_bwd.argtypes = [C.POINTER(AqSeg), i, f, f, C.c_uint, vp, sz, vp]
+        L.aq_synth_bwd_adam.argtypes = [C.POINTER(AqSeg), i, f, f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint, vp, sz, vp]
+        L.aq_synth_bwd_adam.restype = i
         L.aq_synth_workspace_bytes.argtypes = [C.POINTER(AqSeg), i, i]
         L.aq_synth_workspace_bytes.restype = sz
         conv_dims = [i] * 8
@@ -56,6 +63,8 @@ def lib():
         L.aq_conv_fwd_codes.argtypes = [vp, vp, vp, i, vp] + conv_dims + [vp]
         L.aq_conv_dgrad.argtypes = [vp, vp, vp] + conv_dims + [vp]
         L.aq_conv_wgrad.argtypes = [vp, vp, vp] + conv_dims + [vp, sz, vp]
+        L.aq_conv_wgrad_partial.argtypes = [vp, vp] + conv_dims + [vp, sz, C.POINTER(C.c_int), vp]
+        L.aq_conv_wgrad_reduce.argtypes = [C.POINTER(AqWgradJob), i, vp]
         L.aq_conv_wgrad_workspace_bytes.argtypes = conv_dims
         L.aq_conv_wgrad_workspace_bytes.restype = sz
         L.aq_linear_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
@@ -67,7 +76,7 @@ def lib():
         L.aq_bn_workspace_bytes.argtypes = [i, i, i]
         L.aq_bn_workspace_bytes.restype = sz
         for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",
-                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_shortcut_fwd", "aq_shortcut_bwd"):
+                     "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce"):
             getattr(L, name).restype = i
         if L.aq_abi_version() != ABI_VERSION:
             raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))

@@ -293,57 +293,6 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
         }
         ktab[k] = off;
     }
-    // weight panel in fragment order: element (row rl, k) lives at
-    //   As[(((k>>4)*MT + (rl>>4))*64 + ((k>>2)&3)*16 + (rl&15))*4 + (k&3)]
-    // so the 4 consecutive k of one row form one 16-byte LDS store.  Work item = (row, group of 4 k);
-    // eight items per thread are loaded before the first store (the fill is latency-bound).
-    {
-        const int k4n = a.Kpad >> 2, items = 16 * MT * k4n;
-        for (int base = 0; base < items; base += 256 * 8) {
-            float4 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = base + u * 256 + tid;
-                const int rl = it / k4n, k = (it - rl * k4n) * 4;
-                const int row = m0 + rl;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (it < items && row < a.M && k < a.K) {
-                    if (MODE == MODE_FWD && a.vecA) {
-                        v = *reinterpret_cast<const float4 *>(&a.W[(long long)row * a.K + k]);
-                    } else {
-                        float e[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int kk = k + t;
-                            float x = 0.0f;
-                            if (kk < a.K) {
-                                if (MODE == MODE_DGRAD) {
-                                    const int c = kk / 9, tap = kk - 9 * c;
-                                    x = a.W[(long long)c * a.Cin * 9 + row * 9 + (8 - tap)];  // W[co=c, ci=row, flipped tap]
-                                } else if (MODE == MODE_FWD_CODES) {
-                                    x = a.q[a.idx[(long long)row * a.K + kk]];
-                                } else {
-                                    x = a.W[(long long)row * a.K + kk];
-                                }
-                            }
-                            e[t] = x;
-                        }
-                        v = make_float4(e[0], e[1], e[2], e[3]);
-                    }
-                }
-                w[u] = v;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = base + u * 256 + tid;
-                if (it < items) {
-                    const int rl = it / k4n, k = (it - rl * k4n) * 4;
-                    *reinterpret_cast<float4 *>(&As[(((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4]) = w[u];
-                }
-            }
-        }
-    }
-
     // plane geometry of this lane's elements: row inside the image, input column (or -1)
     int rj[J], gxj[J];
 #pragma unroll
@@ -408,6 +357,61 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
         }
     };
 
+    // the first tile's loads are issued before the weight panel's, so both are in flight together
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch_tile(tile);
+
+    // weight panel in fragment order: element (row rl, k) lives at
+    //   As[(((k>>4)*MT + (rl>>4))*64 + ((k>>2)&3)*16 + (rl&15))*4 + (k&3)]
+    // so the 4 consecutive k of one row form one 16-byte LDS store.  Work item = (row, group of 4 k);
+    // eight items per thread are loaded before the first store (the fill is latency-bound).
+    {
+        const int k4n = a.Kpad >> 2, items = 16 * MT * k4n;
+        for (int base = 0; base < items; base += 256 * 8) {
+            float4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * 256 + tid;
+                const int rl = it / k4n, k = (it - rl * k4n) * 4;
+                const int row = m0 + rl;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (it < items && row < a.M && k < a.K) {
+                    if (MODE == MODE_FWD && a.vecA) {
+                        v = *reinterpret_cast<const float4 *>(&a.W[(long long)row * a.K + k]);
+                    } else {
+                        float e[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int kk = k + t;
+                            float x = 0.0f;
+                            if (kk < a.K) {
+                                if (MODE == MODE_DGRAD) {
+                                    const int c = kk / 9, tap = kk - 9 * c;
+                                    x = a.W[(long long)c * a.Cin * 9 + row * 9 + (8 - tap)];  // W[co=c, ci=row, flipped tap]
+                                } else if (MODE == MODE_FWD_CODES) {
+                                    x = a.q[a.idx[(long long)row * a.K + kk]];
+                                } else {
+                                    x = a.W[(long long)row * a.K + kk];
+                                }
+                            }
+                            e[t] = x;
+                        }
+                        v = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
+                w[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * 256 + tid;
+                if (it < items) {
+                    const int rl = it / k4n, k = (it - rl * k4n) * 4;
+                    *reinterpret_cast<float4 *>(&As[(((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4]) = w[u];
+                }
+            }
+        }
+    }
+
     const int nkb = a.Kpad >> 4;
     auto load_a = [&](int kb, float (&av)[MT][4]) {
 #pragma unroll
@@ -427,8 +431,6 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) fetch_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         commit_tile();
         __syncthreads();  // image (and, the first time, tables and weight panel) visible
@@ -749,11 +751,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
 
 // dW[i] = sum over the workgroup slabs.  A workgroup owns 32 consecutive elements; 8 thread rows
 // each add every 8th slab in ascending order, then the 8 running sums are added in order 0..7.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab)
+__device__ __forceinline__ void wgrad_reduce_block(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab, int blk)
 {
     __shared__ float sh[8][33];
     const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + c;
+    const int i = blk * 32 + c;
     float s = 0.0f;
     if (i < n) {
         int b = sg;
@@ -774,6 +776,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         for (int k = 1; k < 8; ++k) t += sh[k][c];
         dW[i] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab)
+{
+    wgrad_reduce_block(part, dW, n, nslab, blockIdx.x);
+}
+
+// the slab reductions of several layers in one launch: job j owns blocks [first[j], first[j+1])
+constexpr int WGRAD_MAX_JOBS = 32;
+struct WgradJobTab {
+    const float *part[WGRAD_MAX_JOBS];
+    float *dW[WGRAD_MAX_JOBS];
+    int n[WGRAD_MAX_JOBS], nslab[WGRAD_MAX_JOBS], first[WGRAD_MAX_JOBS + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJobTab t)
+{
+    int j = 0;
+    while (j + 1 < t.njobs && (int)blockIdx.x >= t.first[j + 1]) ++j;
+    wgrad_reduce_block(t.part[j], t.dW[j], t.n[j], t.nslab[j], blockIdx.x - t.first[j]);
 }
 
 // ------------------------------------------------------------------------------------- host side
@@ -986,6 +1009,10 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
     return ws;
 }
 
+// slab kernel of aq_conv_wgrad; *nslab_out = number of slabs written to workspace ([nslab][Cout*Cin*9])
+static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out);
+
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
                   void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -994,10 +1021,51 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     AQ_REQUIRE(dW, -EFAULT, "aq_conv_wgrad: NULL dW");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nW = Cout * Cin * 9;
-    if (N == 0) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, nullptr, dW, nW, 0);
-        return check_launch("aq_conv_wgrad");
+    int nslab = 0;
+    if (N > 0)
+        if (int rc = wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, st, &nslab)) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, static_cast<const float *>(workspace), dW, nW, nslab);
+    return check_launch("aq_conv_wgrad(reduce)");
+}
+
+int aq_conv_wgrad_partial(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
+                          void *workspace, size_t workspace_bytes, int *nslab, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_conv("aq_conv_wgrad_partial", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(nslab, -EFAULT, "aq_conv_wgrad_partial: NULL nslab");
+    *nslab = 0;
+    if (N == 0) return 0;
+    return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab);
+}
+
+int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
+{
+    using namespace aq;
+    AQ_REQUIRE(njobs >= 0 && (njobs == 0 || jobs), -EINVAL, "aq_conv_wgrad_reduce: bad job list");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < njobs; base += WGRAD_MAX_JOBS) {
+        WgradJobTab t = {};
+        t.njobs = std::min(WGRAD_MAX_JOBS, njobs - base);
+        int blocks = 0;
+        for (int j = 0; j < t.njobs; ++j) {
+            const aq_wgrad_job &q = jobs[base + j];
+            AQ_REQUIRE(q.dW && q.n >= 1 && q.nslab >= 0 && (q.nslab == 0 || q.part), -EINVAL, "aq_conv_wgrad_reduce: bad job %d", base + j);
+            t.part[j] = q.part; t.dW[j] = q.dW; t.n[j] = q.n; t.nslab[j] = q.nslab;
+            t.first[j] = blocks;
+            blocks += (q.n + 31) / 32;
+        }
+        t.first[t.njobs] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
+        if (int rc = check_launch("aq_conv_wgrad_reduce")) return rc;
     }
+    return 0;
+}
+
+static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out)
+{
+    using namespace aq;
     AQ_REQUIRE(x && dy, -EFAULT, "aq_conv_wgrad: NULL pointer");
     WgradArgs a = {};
     a.x = x; a.dy = dy; a.part = static_cast<float *>(workspace);
@@ -1040,9 +1108,8 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     else AQ_WG(1, 18)
 #undef AQ_WGV
 #undef AQ_WG
-    if (int rc = check_launch("aq_conv_wgrad")) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, a.part, dW, nW, (int)grid.x);
-    return check_launch("aq_conv_wgrad(reduce)");
+    *nslab_out = (int)grid.x;
+    return check_launch("aq_conv_wgrad");
 }
 
 } // extern "C"

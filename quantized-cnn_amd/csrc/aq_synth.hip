@@ -34,8 +34,13 @@ struct SegDev {
     const float *p, *q, *dW, *dss;
     float *W, *Wh, *dp, *part;
     uint8_t *idx;
+    float *am, *av;        // Adam first / second moment of p (fused update only)
+    const float *acoef;    // {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} of this segment (fused update only)
     long long rows;
     int L, blk0;
+};
+struct AdamArgs {
+    float omb1, b2, omb2, eps;  // 1-beta1, beta2, 1-beta2, eps
 };
 struct SegTab {
     int nseg, K;
@@ -203,8 +208,14 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
     }
 }
 
-template <int G, int MEM, bool EXACT>
-__global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd)
+// ADAM: instead of (or besides) storing dp_c, apply torch.optim.Adam's update rule to p_c in place
+// (adp_qtz_fan.py:208-209, 291: optimizer_prim = optim.Adam(p_c parameters); .step()):
+//   m += (1-beta1)*(g-m);  v = beta2*v + (1-beta2)*g*g;  p -= step_size * m / (sqrt(v)*rbc2 + eps)
+// with step_size = lr/(1-beta1^t), rbc2 = 1/sqrt(1-beta2^t) prepared per layer by adam_prep_kernel.
+// This removes the dp_c round trip through memory: 6 tensor passes (p, m, v read and written) instead
+// of 2 (K2) + 7 (separate Adam).
+template <int G, int MEM, bool EXACT, bool ADAM>
+__global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd, const AdamArgs ad)
 {
     constexpr int RPP = 64 / G;
     constexpr int LP = 4 * G;
@@ -215,6 +226,13 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     const float *__restrict__ q = tab.s[si].q;
     const float *__restrict__ dW = tab.s[si].dW;
     float *__restrict__ dp = tab.s[si].dp;
+    float *__restrict__ am = tab.s[si].am;
+    float *__restrict__ av = tab.s[si].av;
+    float step_size = 0.0f, rbc2 = 0.0f;
+    if (ADAM) {
+        step_size = tab.s[si].acoef[0];
+        rbc2 = tab.s[si].acoef[1];
+    }
     const float wds = tab.s[si].dss ? __builtin_fmaf(2.0f, tab.s[si].dss[0], wd) : wd;
     float *__restrict__ part = tab.s[si].part;
     const long long rows = tab.s[si].rows;
@@ -240,12 +258,22 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
             constexpr int ub = 8 * decltype(UB)::value;
             float v[8][4];
             float gw[8];
+            float m1[ADAM ? 8 : 1][4], m2[ADAM ? 8 : 1][4];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long long r = row0 + (ub + u) * RPP + gq;
                 const long long rc = r < rows ? r : rows - 1;
                 load_elems<G, MEM>(p, rc, L, j, v[u]);
                 gw[u] = dW ? dW[rc] : 0.0f;
+            }
+            if constexpr (ADAM) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long long r = row0 + (ub + u) * RPP + gq;
+                    const long long rc = r < rows ? r : rows - 1;
+                    load_elems<G, MEM>(am, rc, L, j, m1[u]);
+                    load_elems<G, MEM>(av, rc, L, j, m2[u]);
+                }
             }
             float my_ss = 1.0f;
 #pragma unroll
@@ -283,7 +311,20 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
                 if (r < rows) {
-                    store_elems<G, MEM>(dp, r, L, j, o);
+                    if (!ADAM || dp) store_elems<G, MEM>(dp, r, L, j, o);
+                    if constexpr (ADAM) {
+                        float pn2[4], mo[4], vo[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            mo[k] = __builtin_fmaf(ad.omb1, o[k] - m1[u][k], m1[u][k]);
+                            vo[k] = __builtin_fmaf(ad.omb2 * o[k], o[k], ad.b2 * m2[u][k]);
+                            const float denom = __builtin_fmaf(sqrtf(vo[k]), rbc2, ad.eps);
+                            pn2[k] = v[u][k] - step_size * (mo[k] / denom);
+                        }
+                        store_elems<G, MEM>(const_cast<float *>(p), r, L, j, pn2);
+                        store_elems<G, MEM>(am, r, L, j, mo);
+                        store_elems<G, MEM>(av, r, L, j, vo);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
                 }
@@ -301,6 +342,28 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
             reinterpret_cast<float4 *>(o)[0] = make_float4(accq[0], accq[1], accq[2], accq[3]);
         }
     }
+}
+
+// One thread per layer: advance the layer's Adam step counter (a one-element fp32 tensor, as
+// torch.optim.Adam keeps it with capturable=True) and derive the step-dependent coefficients in double.
+struct AdamPrepTab {
+    float *step[MAX_SEGS];
+    float *coef[MAX_SEGS];
+    int n;
+    double lr, b1, b2;
+};
+__global__ void adam_prep_kernel(const AdamPrepTab t)
+{
+    const int i = threadIdx.x;
+    if (i >= t.n) return;
+    bool first = true;  // a step tensor shared by several layers is advanced once
+    for (int k = 0; k < i; ++k) first = first && t.step[k] != t.step[i];
+    const float tnew = t.step[i][0] + 1.0f;
+    const double bc1 = 1.0 - pow(t.b1, (double)tnew), bc2 = 1.0 - pow(t.b2, (double)tnew);
+    t.coef[i][0] = (float)(t.lr / bc1);
+    t.coef[i][1] = (float)(1.0 / sqrt(bc2));
+    __syncthreads();
+    if (first) t.step[i][0] = tnew;
 }
 
 // Second stage of the cross-row sums: adds the per-wavefront partials of each layer in a fixed
@@ -373,7 +436,7 @@ struct Plan {
 
 static inline long long red_chunks(long long n, int width) { const long long ch = 32LL * (1024 / width); return (n + ch - 1) / ch; }
 
-static int validate(const aq_seg *segs, int nseg, float beta, bool bwd)
+static int validate(const aq_seg *segs, int nseg, float beta, bool bwd, bool adam = false)
 {
     AQ_REQUIRE(segs != nullptr && nseg >= 1 && nseg <= (1 << 12), -EINVAL, "segs must hold 1..4096 segments (got %d)", nseg);
     AQ_REQUIRE(beta == beta && std::abs(beta) <= AQ_MAX_ABS_BETA, -EDOM, "beta=%g outside [-%g, %g]", (double)beta,
@@ -384,7 +447,11 @@ static int validate(const aq_seg *segs, int nseg, float beta, bool bwd)
         AQ_REQUIRE(s.rows >= 0, -EINVAL, "segment %d: negative row count", i);
         AQ_REQUIRE(s.rows == 0 || (s.p_c && s.q), -EFAULT, "segment %d: p_c / q is NULL", i);
         AQ_REQUIRE(((uintptr_t)s.p_c & 3) == 0 && ((uintptr_t)s.q & 3) == 0, -EINVAL, "segment %d: misaligned pointer", i);
-        if (bwd) AQ_REQUIRE(s.rows == 0 || s.dp_c, -EFAULT, "segment %d: dp_c is NULL", i);
+        if (bwd && !adam) AQ_REQUIRE(s.rows == 0 || s.dp_c, -EFAULT, "segment %d: dp_c is NULL", i);
+        if (adam) {
+            AQ_REQUIRE(s.adam_step && (s.rows == 0 || (s.adam_m && s.adam_v)), -EFAULT, "segment %d: Adam state is NULL", i);
+            AQ_REQUIRE(((uintptr_t)s.adam_m & 3) == 0 && ((uintptr_t)s.adam_v & 3) == 0, -EINVAL, "segment %d: misaligned Adam state", i);
+        }
     }
     return 0;
 }
@@ -412,12 +479,16 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
 }
 
 template <bool BWD>
-static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, hipStream_t st)
+static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, const AdamArgs *adam,
+                         hipStream_t st)
 {
+    const AdamArgs ad = adam ? *adam : AdamArgs{};
 #define AQ_LAUNCH(GG, MM)                                                                                             \
     if (BWD) {                                                                                                        \
-        if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd); \
-        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd);   \
+        if (adam && exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        else if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        else if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
     } else if (hard)                                                                                                  \
         hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
     else if (exact)                                                                                                   \
@@ -435,16 +506,39 @@ static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &ta
 #undef AQ_LAUNCH
 }
 
+struct AdamHost {
+    double lr, b1, b2, eps;
+};
+
 template <bool BWD>
-static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace, size_t workspace_bytes, hipStream_t st)
+static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flags, void *workspace, size_t workspace_bytes, hipStream_t st,
+               const AdamHost *adam = nullptr)
 {
     const bool exact = (flags & AQ_FLAG_EXACT) != 0;
-    if (int rc = validate(segs, nseg, beta, BWD)) return rc;
+    if (int rc = validate(segs, nseg, beta, BWD, adam != nullptr)) return rc;
     static thread_local Plan pl;
     make_plan(segs, nseg, BWD, pl);
+    const size_t coef_off = pl.bytes;  // Adam coefficients: two floats per segment behind the partials
+    if (adam) pl.bytes += ((size_t)nseg * 2 * sizeof(float) + 255) & ~(size_t)255;
     AQ_REQUIRE(pl.bytes == 0 || (workspace && workspace_bytes >= pl.bytes), -ENOSPC, "workspace too small: need %zu bytes, got %zu",
                pl.bytes, workspace_bytes);
     AQ_REQUIRE(((uintptr_t)workspace & 15) == 0, -EINVAL, "workspace must be 16-byte aligned");
+    AdamArgs ad_dev = {};
+    float *coef = nullptr;
+    if (adam) {
+        AQ_REQUIRE(nseg <= MAX_SEGS, -E2BIG, "fused Adam update: at most %d layers per call (got %d)", MAX_SEGS, nseg);
+        AQ_REQUIRE(adam->lr >= 0 && adam->b1 >= 0 && adam->b1 < 1 && adam->b2 >= 0 && adam->b2 < 1 && adam->eps >= 0, -EDOM,
+                   "fused Adam update: lr=%g betas=(%g, %g) eps=%g out of range", adam->lr, adam->b1, adam->b2, adam->eps);
+        coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + coef_off);
+        AdamPrepTab t = {};
+        t.n = nseg; t.lr = adam->lr; t.b1 = adam->b1; t.b2 = adam->b2;
+        for (int i = 0; i < nseg; ++i) {
+            t.step[i] = segs[i].adam_step;
+            t.coef[i] = coef + 2 * i;
+        }
+        hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, st, t);
+        ad_dev.omb1 = (float)(1.0 - adam->b1); ad_dev.b2 = (float)adam->b2; ad_dev.omb2 = (float)(1.0 - adam->b2); ad_dev.eps = (float)adam->eps;
+    }
 
     // streaming cache policy when the tensors cannot stay in the 256 MiB last-level cache anyway
     long long total_bytes = 0;
@@ -460,7 +554,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             int nblocks = 0;
             bool hard = false;
             auto flush = [&]() {
-                if (tab.nseg) launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, st);
+                if (tab.nseg) launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st);
                 tab.nseg = 0;
                 nblocks = 0;
                 hard = false;
@@ -470,9 +564,11 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                 if (s.rows == 0 || lanes_for(s.L) != G) continue;
                 bool v = (s.L == 4 * G) && (((uintptr_t)s.p_c & 15) == 0);
                 if (BWD) v = v && (((uintptr_t)s.dp_c & 15) == 0);
+                if (adam) v = v && (((uintptr_t)s.adam_m & 15) == 0) && (((uintptr_t)s.adam_v & 15) == 0);
                 if ((int)v != vec) continue;
                 SegDev &d = tab.s[tab.nseg];
                 d.p = s.p_c; d.q = s.q; d.dW = s.dW; d.dss = s.dsumsq; d.W = s.W; d.Wh = s.W_hard; d.dp = s.dp_c; d.idx = s.idx;
+                d.am = adam ? s.adam_m : nullptr; d.av = adam ? s.adam_v : nullptr; d.acoef = adam ? coef + 2 * i : nullptr;
                 const bool need = BWD ? s.dq != nullptr : s.sumsq != nullptr;
                 d.part = need ? reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.off[i]) : nullptr;
                 d.rows = s.rows; d.L = s.L; d.blk0 = nblocks;
@@ -552,12 +648,19 @@ int aq_synth_bwd(const aq_seg *segs, int nseg, float beta, float wd, unsigned fl
     return aq::run<true>(segs, nseg, beta, wd, flags, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int aq_synth_bwd_adam(const aq_seg *segs, int nseg, float beta, float wd, double lr, double beta1, double beta2, double eps, unsigned flags,
+                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    const aq::AdamHost ad{lr, beta1, beta2, eps};
+    return aq::run<true>(segs, nseg, beta, wd, flags, workspace, workspace_bytes, static_cast<hipStream_t>(stream), &ad);
+}
+
 size_t aq_synth_workspace_bytes(const aq_seg *segs, int nseg, int backward)
 {
     if (!segs || nseg < 1 || nseg > (1 << 12)) return 0;
     static thread_local aq::Plan pl;
     aq::make_plan(segs, nseg, backward != 0, pl);
-    return pl.bytes;
+    return pl.bytes + (backward == 2 ? (((size_t)nseg * 2 * sizeof(float) + 255) & ~(size_t)255) : 0);
 }
 
 } // extern "C"

@@ -32,6 +32,20 @@ def set_dW_reduce_hook(fn):
     _dW_reduce_hook = fn
 
 
+# When a list, the convolution backward passes of layers that write into a flat dW buffer only run the
+# first stage of the weight gradient and append (workspace, dW slot, slabs) here; the owner of the list
+# (train.FusedTrainStep) reduces all of them with one launch after backward.  The slots hold no valid
+# gradient until then, so this is only for callers that read them afterwards.
+_wgrad_deferred = None
+
+
+def defer_wgrad_reductions(jobs):
+    """jobs: a list to collect into, or None to switch deferral off.  Returns the previous setting."""
+    global _wgrad_deferred
+    prev, _wgrad_deferred = _wgrad_deferred, jobs
+    return prev
+
+
 # ---------------------------------------------------------------------------------------- autograd
 
 class _SynthAll(torch.autograd.Function):
@@ -107,7 +121,14 @@ class _Conv3x3(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
-        dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot) if ctx.needs_input_grad[1] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            if _wgrad_deferred is not None and ctx.dW_slot is not None:
+                ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
+                _wgrad_deferred.append((ws, ctx.dW_slot, nslab))
+                dW = ctx.dW_slot
+            else:
+                dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot)
         return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None)
 
 

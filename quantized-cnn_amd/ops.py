@@ -113,6 +113,48 @@ def synth_backward(p_list, q_list, beta, dW_list, wd=0.0, need_dq=None, out_dp=N
     return dp, dq
 
 
+def synth_backward_adam(p_list, q_list, beta, dW_list, exp_avg, exp_avg_sq, steps, lr, betas=(0.9, 0.999), eps=1e-8, wd=0.0,
+                        need_dq=None, dsumsq=None, exact=None, out_dq=None, out_dp=None):
+    """synth_backward with torch.optim.Adam's update of p_c fused in (adp_qtz_fan.py:208-209, 291):
+    p_list[i], exp_avg[i], exp_avg_sq[i] are updated in place and steps[i] (one-element fp32 device
+    tensors, the optimizer's state["step"]) are advanced by one.  Returns dq_list; the gradient dp_c is
+    only stored when out_dp is given."""
+    n = len(p_list)
+    if n > 24:
+        raise ValueError("synth_backward_adam: at most 24 layers per call (got %d)" % n)
+    segs = _seg_array(p_list, q_list)
+    dev = p_list[0].device
+    need_dq = [True] * n if need_dq is None else list(need_dq)
+    if out_dq is not None:
+        dq = [o if need else None for o, need in zip(out_dq, need_dq)]
+    else:
+        dq = [torch.empty_like(q) if need else None for q, need in zip(q_list, need_dq)]
+    for i in range(n):
+        if dW_list[i] is not None:
+            if dW_list[i].numel() != segs[i].rows:
+                raise ValueError("dW[%d] has %d elements, expected %d" % (i, dW_list[i].numel(), segs[i].rows))
+            segs[i].dW = _lib.ptr(dW_list[i], name="dW[%d]" % i)
+        for t, what in ((exp_avg[i], "exp_avg"), (exp_avg_sq[i], "exp_avg_sq")):
+            if t.shape != p_list[i].shape:
+                raise ValueError("%s[%d] has shape %s, expected %s" % (what, i, tuple(t.shape), tuple(p_list[i].shape)))
+        segs[i].adam_m = _lib.ptr(exp_avg[i], name="exp_avg[%d]" % i)
+        segs[i].adam_v = _lib.ptr(exp_avg_sq[i], name="exp_avg_sq[%d]" % i)
+        if steps[i].numel() != 1:
+            raise ValueError("steps[%d] must hold one element" % i)
+        segs[i].adam_step = _lib.ptr(steps[i], name="step[%d]" % i)
+        if out_dp is not None:
+            segs[i].dp_c = _lib.ptr(out_dp[i], name="dp_c[%d]" % i)
+        if dsumsq is not None:
+            segs[i].dsumsq = _lib.ptr(dsumsq, name="dsumsq") + 4 * i
+        if dq[i] is not None:
+            segs[i].dq = _lib.ptr(dq[i], name="dq[%d]" % i)
+    nbytes = _lib.lib().aq_synth_workspace_bytes(segs, n, 2)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().aq_synth_bwd_adam(segs, n, float(beta), float(wd), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                            _flags(exact), ws.data_ptr(), nbytes, _lib.stream()))
+    return dq
+
+
 # ------------------------------------------------------------------------------------ convolution
 
 def _conv_dims(x_shape, Cout, stride):
@@ -169,6 +211,32 @@ def conv_wgrad(x, dy, stride=1, out=None):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     _lib.check(_lib.lib().aq_conv_wgrad(_lib.ptr(x, name="x"), _lib.ptr(dy, name="dy"), _lib.ptr(dW, name="dW"), *dims, ws.data_ptr(), nbytes, _lib.stream()))
     return dW
+
+
+def conv_wgrad_partial(x, dy, stride=1):
+    """First stage of conv_wgrad only: -> (workspace tensor holding the slabs, number of slabs).  The
+    caller reduces them later with conv_wgrad_reduce (several layers in one launch)."""
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):
+        raise ValueError("conv_wgrad_partial: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    dims = _conv_dims(x.shape, Cout, stride)
+    nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    nslab = C.c_int(0)
+    _lib.check(_lib.lib().aq_conv_wgrad_partial(_lib.ptr(x, name="x"), _lib.ptr(dy, name="dy"), *dims, ws.data_ptr(), nbytes, C.byref(nslab),
+                                                _lib.stream()))
+    return ws, nslab.value
+
+
+def conv_wgrad_reduce(jobs):
+    """jobs: list of (workspace, dW tensor, nslab) from conv_wgrad_partial; one launch per 32 jobs."""
+    if not jobs:
+        return
+    arr = (_lib.AqWgradJob * len(jobs))()
+    for j, (ws, dW, nslab) in enumerate(jobs):
+        arr[j].part, arr[j].dW = ws.data_ptr(), _lib.ptr(dW, name="dW")
+        arr[j].n, arr[j].nslab = dW.numel(), nslab
+    _lib.check(_lib.lib().aq_conv_wgrad_reduce(arr, len(jobs), _lib.stream()))
 
 
 # ----------------------------------------------------------------------------------------- linear

@@ -201,7 +201,9 @@ class FusedTrainStep:
     use_graph=False the same two phases run eagerly.
     """
 
-    def __init__(self, model, config, module, dp=None, use_graph=True):
+    def __init__(self, model, config, module, dp=None, use_graph=True, fuse_adam=True):
+        """fuse_adam: apply optimizer_prim's Adam update of p_c inside the synthesis-gradient kernel (the
+        optimizer object keeps its state tensors and state_dict format; its step() is not called)."""
         self.model, self.config, self.module, self.dp = model, config, module, dp
         self.use_graph = use_graph
         self.criterion = nn.CrossEntropyLoss()
@@ -224,7 +226,9 @@ class FusedTrainStep:
             self.slots.append(self.g_flat[off:off + n].view(p.shape[:-1]))
             off += n
         self.nW = nW
-        self.dp_out = [torch.zeros_like(p) for p in self.ps]
+        g0 = self.opts[0].param_groups[0]
+        self.fuse_adam = bool(fuse_adam) and len(self.ps) <= 24 and not (g0["amsgrad"] or g0["maximize"] or g0["weight_decay"])
+        self.dp_out = None if self.fuse_adam else [torch.zeros_like(p) for p in self.ps]
         self.dq_out = [torch.zeros_like(q) if q.requires_grad else None for q in self.qs]
         self.dss = torch.full((len(self.ps),), float(config.l2_reg), dtype=torch.float32, device=dev)
         self._graphs = None
@@ -251,7 +255,14 @@ class FusedTrainStep:
         self.model._synth_cache = None
         logits = self.model.forward_body(x)
         ce = self.criterion(logits, y)
-        ce.backward()
+        jobs = []
+        prev = layers.defer_wgrad_reductions(jobs)
+        try:
+            ce.backward()
+        finally:
+            layers.defer_wgrad_reductions(prev)
+        ops.conv_wgrad_reduce(jobs)  # the slab sums of all quantized convolutions in one launch
+        del jobs
         for w in leaves:
             w.grad = None
         if self._exchange:
@@ -278,14 +289,23 @@ class FusedTrainStep:
             torch._foreach_copy_([p.grad for p in self.dense], views)
         if self.dense_reg:
             torch._foreach_add_([p.grad for p in self.dense_reg], [p.detach() for p in self.dense_reg], alpha=2.0 * float(self.config.l2_reg))
-        ops.synth_backward([p.detach() for p in self.ps], [q.detach() for q in self.qs], float(self.module.beta),
-                           self.slots, 0.0, need_dq=need_dq, out_dp=self.dp_out, out_dq=self.dq_out, dsumsq=self.dss)
-        for p, g in zip(self.ps, self.dp_out):
-            p.grad = g
+        ps, qs = [p.detach() for p in self.ps], [q.detach() for q in self.qs]
+        if self.fuse_adam:
+            self._ensure_adam_state()
+            grp = self.opts[0].param_groups[0]
+            st = [self.opts[0].state[p] for p in self.ps]
+            ops.synth_backward_adam(ps, qs, float(self.module.beta), self.slots, [t["exp_avg"] for t in st], [t["exp_avg_sq"] for t in st],
+                                    [t["step"] for t in st], lr=grp["lr"], betas=grp["betas"], eps=grp["eps"], need_dq=need_dq,
+                                    out_dq=self.dq_out, dsumsq=self.dss)
+        else:
+            ops.synth_backward(ps, qs, float(self.module.beta), self.slots, 0.0, need_dq=need_dq, out_dp=self.dp_out, out_dq=self.dq_out,
+                               dsumsq=self.dss)
+            for p, g in zip(self.ps, self.dp_out):
+                p.grad = g
         for q, g in zip(self.qs, self.dq_out):
             if g is not None:
                 q.grad = g
-        for o in self.opts:
+        for o in (self.opts[1:] if self.fuse_adam else self.opts):
             o.step()
 
     def _comm(self):
@@ -310,20 +330,26 @@ class FusedTrainStep:
         self._graphs[1].replay()
         return self.loss
 
-    def _capture(self, x, y):
-        self._sx, self._sy = x.clone(), y.clone()
-        for o in self.opts:  # Adam creates its state lazily: create it here so that capture does not
+    def _ensure_adam_state(self):
+        """Adam creates its state lazily in step(); create it up front (same tensors, same state_dict
+        layout) for the graph capture and for the fused p_c update."""
+        for o in self.opts:
             for group in o.param_groups:
                 for p in group["params"]:
                     if p.requires_grad and len(o.state[p]) == 0:
                         o.state[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                         o.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                         o.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _capture(self, x, y):
+        self._sx, self._sy = x.clone(), y.clone()
+        self._ensure_adam_state()
         for q, g in zip(self.qs, self.dq_out):
             if g is not None:
                 q.grad = g
-        for p, g in zip(self.ps, self.dp_out):
-            p.grad = g
+        if self.dp_out is not None:
+            for p, g in zip(self.ps, self.dp_out):
+                p.grad = g
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         torch.cuda.synchronize()

@@ -381,3 +381,87 @@ def test_shortcut_pool_pad_forward_backward(shape):
     wdx = np.zeros(shape, np.float32)
     wdx[:, :, :2 * Ho, :2 * Wo] = np.repeat(np.repeat(dy[:, front:front + Cn], 2, axis=2), 2, axis=3) * 0.25
     assert np.array_equal(dx, wdx)
+
+
+def test_wgrad_partial_plus_batched_reduce_equals_wgrad():
+    rs = np.random.RandomState(12)
+    jobs, want, outs = [], [], []
+    for (N, cin, cout, s, H) in [(16, 16, 16, 1, 32), (16, 16, 32, 2, 32), (16, 32, 32, 1, 16), (8, 64, 64, 1, 8), (2, 3, 5, 1, 7)] * 8:
+        x, dy_shape = cu(rs.standard_normal((N, cin, H, H))), ops.conv_out_shape((N, cin, H, H), cout, s)
+        dy = cu(rs.standard_normal(dy_shape))
+        want.append(ops.conv_wgrad(x, dy, s))
+        ws, nslab = ops.conv_wgrad_partial(x, dy, s)
+        out = torch.empty_like(want[-1])
+        jobs.append((ws, out, nslab))
+        outs.append(out)
+    assert len(jobs) == 40  # more than one launch of 32 jobs
+    ops.conv_wgrad_reduce(jobs)
+    for a, b in zip(outs, want):
+        assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ Adam fused into the synthesis gradient
+# gradient bit-exact as in synth_backward (exact mode); the Adam arithmetic runs in fp32 with fused
+# multiply-adds against the oracle's double evaluation: |dp| <= 2e-6*lr-scale, moments rel 1e-6.
+
+@pytest.mark.parametrize("L", [4, 31, 32, 64, 100])
+def test_synth_backward_adam_vs_oracle(L):
+    rs = np.random.RandomState(900 + L)
+    rows = 777
+    p0 = rs.standard_normal((rows, L)).astype(np.float32)
+    q = rand_levels(rs, L)
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    p, m, v = cu(p0), torch.zeros(rows, L, device=DEV), torch.zeros(rows, L, device=DEV)
+    step = torch.zeros((), device=DEV)
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for t in range(1, 4):
+        dW = rs.standard_normal(rows).astype(np.float32)
+        dp_ref, dq_ref = ops.synth_backward([p.clone()], [cu(q)], 2.0, [cu(dW)], 1e-3, exact=True)
+        g_dev = torch.empty_like(p)
+        dq = ops.synth_backward_adam([p], [cu(q)], 2.0, [cu(dW)], [m], [v], [step], lr, (b1, b2), eps, wd=1e-3, exact=True, out_dp=[g_dev])
+        assert float(step) == t
+        assert torch.equal(g_dev, dp_ref[0])          # same gradient, bit for bit
+        assert torch.equal(dq[0], dq_ref[0])
+        g_or, _ = O.synth_bwd(po, q, 2.0, dW, 1e-3)   # oracle gradient at the oracle's own parameters
+        O.adam_step(po, g_or, mo, vo, t, lr, b1, b2, eps)
+        assert np.abs(p.cpu().numpy() - po).max() <= 2e-4 * lr * t + 1e-6, t   # noise-level gradients may flip the +-lr step
+        frac_off = (np.abs(p.cpu().numpy() - po) > 1e-6).mean()
+        assert frac_off <= 0.01, (t, frac_off)
+        assert np.abs(m.cpu().numpy() - mo).max() <= 1e-5 * max(np.abs(mo).max(), 1e-6)
+        assert np.abs(v.cpu().numpy() - vo).max() <= 1e-5 * max(np.abs(vo).max(), 1e-12)
+
+
+def test_synth_backward_adam_equals_torch_fused_adam_on_resnet20_shapes():
+    """All 19 layers in one call against synth_backward followed by torch.optim.Adam(fused=True)."""
+    torch.manual_seed(4)
+    shapes = [(16, 16, 3, 3)] * 6 + [(32, 16, 3, 3)] + [(32, 32, 3, 3)] * 5 + [(64, 32, 3, 3)] + [(64, 64, 3, 3)] * 5 + [(64, 10)]
+    L = 32
+    ps = [torch.rand(*s, L, device=DEV) for s in shapes]
+    qs = [torch.randn(L, device=DEV) * 0.2 for _ in shapes]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref_p, lr=1e-2, fused=True)
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    steps = [torch.zeros((), device=DEV) for _ in ps]
+    for t in range(3):
+        dW = [torch.randn(s, device=DEV) for s in shapes]
+        dp, _ = ops.synth_backward([p.detach() for p in ref_p], qs, 1.0, dW, 1e-3)
+        for p, g in zip(ref_p, dp):
+            p.grad = g
+        opt.step()
+        ops.synth_backward_adam(ps, qs, 1.0, dW, m, v, steps, 1e-2, wd=1e-3)
+        for a, b in zip(ps, ref_p):
+            d = (a - b.detach()).abs()
+            assert d.max().item() <= 2.1e-2 * (t + 1)
+            assert (d > 2e-6).float().mean().item() <= 0.01
+    st = opt.state[ref_p[0]]
+    assert torch.allclose(m[0], st["exp_avg"], rtol=1e-4, atol=1e-9) and torch.allclose(v[0], st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    assert float(steps[0]) == float(st["step"]) == 3
+
+
+def test_synth_backward_adam_argument_errors():
+    p, q = torch.rand(8, 32, device=DEV), torch.rand(32, device=DEV)
+    with pytest.raises(ValueError, match="exp_avg"):
+        ops.synth_backward_adam([p], [q], 1.0, [None], [torch.zeros(8, 31, device=DEV)], [torch.zeros_like(p)], [torch.zeros((), device=DEV)], 1e-2)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.synth_backward_adam([p], [q], 1.0, [None], [torch.zeros_like(p)], [torch.zeros_like(p)], [torch.zeros((), device=DEV)], 1e-2, betas=(1.5, 0.9))

@@ -158,14 +158,17 @@ def test_module_api_details():
 
 @pytest.mark.parametrize("variant", ["fan", "fix", "hint"])
 @pytest.mark.parametrize("graph", [False, True])
-def test_fused_step_matches_reference_curve(golden, variant, graph):
-    """FusedTrainStep (two HIP graphs around the gradient exchange) against the same reference run."""
+@pytest.mark.parametrize("fuse_adam", [True, False])
+def test_fused_step_matches_reference_curve(golden, variant, graph, fuse_adam):
+    """FusedTrainStep (two HIP graphs around the gradient exchange; Adam of p_c inside the synthesis
+    gradient kernel or as a separate optimizer step) against the same reference run."""
     g = golden("train")
     k = variant + "_"
     mod, c, model = build(variant, g)
     model.train()
     x, y = torch.from_numpy(g[k + "x"]).cuda(), torch.from_numpy(g[k + "y"]).cuda()
-    step = FusedTrainStep(model, c, mod, use_graph=graph)
+    step = FusedTrainStep(model, c, mod, use_graph=graph, fuse_adam=fuse_adam)
+    assert step.fuse_adam == fuse_adam
     losses, regs = [], []
     for it in range(int(g["steps"])):
         if it == 3:
@@ -181,6 +184,13 @@ def test_fused_step_matches_reference_curve(golden, variant, graph):
     assert np.abs(np.array(regs) - g[k + "reg"]).max() <= 1e-4 * g[k + "reg"].max()
     sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
     assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+    named = dict(model.named_parameters())
+    for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
+        assert close(named[n + ".p_c"].detach().reshape(-1)[:4096].cpu().numpy(), g[k + "p_final_head_" + n], 2e-2), n
+    # the optimizer object keeps torch's state layout (checkpoint interchange, adp_qtz_fan.py:337)
+    sd = step.opts[0].state_dict()
+    assert len(sd["state"]) == 19 and set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == float(int(g["steps"]))
 
 
 def test_residual_blocks_match_reference_fixture(golden):
