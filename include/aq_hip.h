@@ -162,6 +162,15 @@ int aq_shortcut_fwd(const float *x, float *y, int N, int C, int H, int Wd, int p
 int aq_shortcut_bwd(const float *dy, float *dx, int N, int C, int H, int Wd, int pad_front, int pad_back,
                     void *stream);
 
+/* Packed storage of hard-mode weights: the codes idx = argmax s_c (adp_qtz_fan_test.py:304; values < L)
+ * as a little-endian bit stream, `bits` (1..8; 5 for L = 31 / 32) bits per code, code i in stream bits
+ * [i*bits, (i+1)*bits); the layer's weights are q_level[idx] (:305).  out / packed hold
+ * aq_packed_bytes(n, bits) = ceil(n*bits/8) bytes.  The reference keeps no packed form on disk; this is
+ * the export format of this library. */
+size_t aq_packed_bytes(long long n, int bits);
+int aq_pack_codes(const uint8_t *idx, long long n, int bits, uint8_t *out, void *stream);
+int aq_unpack_codes(const uint8_t *packed, long long n, int bits, uint8_t *idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,6 +208,20 @@ def adam_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
     lib().aqo_adam_step(p.ctypes.data_as(fp), gp, m.ctypes.data_as(fp), v.ctypes.data_as(fp), p.size, int(t), lr, b1, b2, eps)
 
 
+def pack_codes(idx, bits):
+    """Little-endian bit stream of `bits`-bit codes: code i occupies stream bits [i*bits, (i+1)*bits)."""
+    idx = np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1)
+    b = np.unpackbits(idx[:, None], axis=1, bitorder="little")[:, :bits]
+    return np.packbits(b.reshape(-1), bitorder="little")
+
+
+def unpack_codes(packed, n, bits):
+    b = np.unpackbits(np.ascontiguousarray(packed, dtype=np.uint8), bitorder="little")[:n * bits].reshape(n, bits)
+    full = np.zeros((n, 8), np.uint8)
+    full[:, :bits] = b
+    return np.packbits(full, axis=1, bitorder="little").reshape(-1)
+
+
 def levels_fix(s, num_level, liar=True):
     """adp_qtz_fix.py:661-665: [-2^t .. descending magnitude], 0, [2^t ..]; num_level-1 entries."""
     import math

@@ -21,6 +21,7 @@ EXPORTS = (
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
     "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
+    "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes",
 )
 
 
@@ -73,6 +74,11 @@ def lib():
         L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, vp]
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+        L.aq_packed_bytes.argtypes = [C.c_longlong, i]
+        L.aq_packed_bytes.restype = sz
+        L.aq_pack_codes.argtypes = [vp, C.c_longlong, i, vp, vp]
+        L.aq_unpack_codes.argtypes = [vp, C.c_longlong, i, vp, vp]
+        L.aq_pack_codes.restype = L.aq_unpack_codes.restype = i
         L.aq_bn_workspace_bytes.argtypes = [i, i, i]
         L.aq_bn_workspace_bytes.restype = sz
         for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",

@@ -243,6 +243,24 @@ class _QuantBase(nn.Module):
         self.q_level = nn.Parameter(torch.empty(L), requires_grad=self.variant != "fix")
         self.mode = config.mode
         self._shared = None  # (W, dW_slot) handed down by the owning ResNet for the current step
+        self._codes = None   # hard mode: pinned {"idx": [codes], "W_hard": [q[idx]], "q": levels} (see set_codes)
+
+    def set_codes(self, idx, q_level=None):
+        """Hard mode only: pin the layer's codes (uint8, shape p_c.shape[:-1]) and codebook, e.g. from a
+        packed export, so that forward passes no longer derive them from p_c.  set_codes(None) returns to
+        synthesising from p_c."""
+        if idx is None:
+            self._codes = None
+            return
+        if self.mode != "test":
+            raise RuntimeError("set_codes: the layer was built with mode=%r; codes are used in mode='test' only" % (self.mode,))
+        q = (self.q_level.detach() if q_level is None else q_level).to(idx.device, torch.float32).contiguous()
+        if tuple(idx.shape) != tuple(self.p_c.shape[:-1]) or idx.dtype != torch.uint8:
+            raise ValueError("set_codes: need uint8 codes of shape %s" % (tuple(self.p_c.shape[:-1]),))
+        if int(idx.max()) >= q.numel():
+            raise ValueError("set_codes: code %d outside the %d-entry codebook" % (int(idx.max()), q.numel()))
+        idx = idx.contiguous()
+        self._codes = {"idx": [idx], "W_hard": [q[idx.long()]], "q": q}
 
     def _init_levels(self, config, num_level, fan_in, s):
         with torch.no_grad():
@@ -265,6 +283,8 @@ class _QuantBase(nn.Module):
             W, _ = _SynthAll.apply(self.current_beta(), holder, self.p_c, self.q_level)
             return W, holder["slots"][0]
         if self.mode == "test":
+            if self._codes is not None:
+                return self._codes, None
             out = ops.synth_forward([self.p_c.detach()], [self.q_level.detach()], self.current_beta(), soft=False, codes=True)
             return out, None
         raise ValueError("Unknown run mode \"{}\"".format(self.mode))
@@ -285,7 +305,7 @@ class QConv2d(_QuantBase):
         w, slot = self.synthesize()
         if self.mode == "train":
             return _Conv3x3.apply(x, w, self.stride, slot, res)
-        y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], self.q_level.detach(), self.stride)
+        y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], w["q"] if "q" in w else self.q_level.detach(), self.stride)
         return y if res is None else y + res
 
 

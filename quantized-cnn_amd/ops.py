@@ -331,3 +331,28 @@ def shortcut_backward(dy, x_shape, pad_front, pad_back):
     _lib.check(_lib.lib().aq_shortcut_bwd(_lib.ptr(dy, name="dy"), _lib.ptr(dx), int(N), int(Cn), int(H), int(Wd), int(pad_front), int(pad_back),
                                           _lib.stream()))
     return dx
+
+
+# ---------------------------------------------------------------------------------- packed codes
+
+def code_bits(L):
+    """Bits per code for L levels: ceil(log2 L), at least 1."""
+    return max(1, (int(L) - 1).bit_length())
+
+
+def pack_codes(idx, bits):
+    """uint8 codes (any shape) -> uint8 bit stream of ceil(n*bits/8) bytes (little-endian, code i in
+    bits [i*bits, (i+1)*bits))."""
+    n = idx.numel()
+    out = torch.empty(_lib.lib().aq_packed_bytes(n, int(bits)), dtype=torch.uint8, device=idx.device)
+    _lib.check(_lib.lib().aq_pack_codes(_lib.ptr(idx, torch.uint8, "idx"), n, int(bits), _lib.ptr(out, torch.uint8), _lib.stream()))
+    return out
+
+
+def unpack_codes(packed, n, bits):
+    if packed.numel() != _lib.lib().aq_packed_bytes(int(n), int(bits)):
+        raise ValueError("unpack_codes: %d bytes given, %d codes of %d bits need %d" % (
+            packed.numel(), n, bits, _lib.lib().aq_packed_bytes(int(n), int(bits))))
+    idx = torch.empty(int(n), dtype=torch.uint8, device=packed.device)
+    _lib.check(_lib.lib().aq_unpack_codes(_lib.ptr(packed, torch.uint8, "packed"), int(n), int(bits), _lib.ptr(idx, torch.uint8), _lib.stream()))
+    return idx

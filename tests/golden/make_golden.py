@@ -437,10 +437,62 @@ def gen_block(torch):
     print("block.npz: %d cases" % len(cases))
 
 
+def gen_ckpt(torch):
+    """A training checkpoint written the way the reference's train() writes it (adp_qtz_fan.py:331-340)
+    after two optimisation steps of a small ResNet (n=1 block per stage, 4 levels), plus what the
+    reference computes from that state: loss / logits of the next training step, and the hard-mode
+    logits of adp_qtz_fan_test.py's model loaded from the same file (eval mode)."""
+    mod = load_ref("adp_qtz_fan.py")
+    modt = load_ref("adp_qtz_fan_test.py")
+    c = cfg(L=4, Lfc=4)
+    mod.beta = 2
+    rs = np.random.RandomState(31)
+    model = mod.ResNet(c, 1)
+    fill_model_from_numpy(torch, model, 5)
+    model.train()
+    B = 6
+    x = torch.from_numpy(rs.standard_normal((B, 3, 32, 32)).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, 10, B).astype(np.int64))
+    named = list(model.named_parameters())
+    o1 = torch.optim.Adam([p for n, p in named if "p_c" in n], lr=1e-2)
+    o2 = torch.optim.Adam([p for n, p in named if "q_level" in n], lr=1e-3)
+    o3 = torch.optim.Adam([p for n, p in named if "p_c" not in n and "q_level" not in n], lr=1e-2)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def step():
+        logits = model.forward(x)
+        loss = crit(logits, y) + mod.model_loss(c, mod.beta, model)
+        loss.backward()
+        o1.step(); o2.step(); o3.step()
+        o1.zero_grad(); o2.zero_grad(); o3.zero_grad()
+        return loss.item(), logits.detach().numpy().copy()
+
+    losses = [step()[0], step()[0]]
+    path = os.path.join(OUT, "ckpt_fan.pt")
+    torch.save({
+        "beta": mod.beta, "epoch": 3, "iter_idx": 1, "best_val_acc": np.mean([np.float32(12.5), np.float32(25.0)]),
+        "model": model.state_dict(), "optimizer_prim": o1.state_dict(), "optimizer_q": o2.state_dict(),
+        "optimizer": o3.state_dict(),
+    }, path)
+    # hard-mode logits of the test script's model with the same state (eval: running statistics)
+    modt.beta = 2
+    mt = modt.ResNet(c, 1)
+    mt.load_state_dict(model.state_dict())
+    mt.eval()
+    with torch.no_grad():
+        hard = mt.forward(x).numpy().copy()
+    l3, logits3 = step()
+    out = {"x": f32(x.numpy()), "y": y.numpy(), "losses_before": np.array(losses), "loss_next": np.float64(l3),
+           "logits_next": f32(logits3), "hard_logits_eval": f32(hard), "beta": np.int64(2),
+           "p_sum_after_next": np.array([float(p.detach().double().sum()) for n, p in named])}
+    np.savez_compressed(os.path.join(OUT, "ckpt.npz"), **out)
+    print("ckpt_fan.pt: %d bytes; losses %s -> %.6f" % (os.path.getsize(path), losses, l3))
+
+
 def main():
     import torch
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block"]
+    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block", "ckpt"]
     for w in which:
         globals()["gen_" + w](torch)
 
