@@ -171,6 +171,26 @@ size_t aq_packed_bytes(long long n, int bits);
 int aq_pack_codes(const uint8_t *idx, long long n, int bits, uint8_t *out, void *stream);
 int aq_unpack_codes(const uint8_t *packed, long long n, int bits, uint8_t *idx, void *stream);
 
+/* One training batch from the raw image array, replacing the reference's per-image CPU transforms
+ * RandomCrop(32, padding=4) + RandomHorizontalFlip() + ToTensor() + Normalize(mean, std)
+ * (adp_qtz_fan.py:164-169) and the DataLoader gather (:178-183):
+ *   data  [n_images, H, W, C] uint8, channels last (the layout of adp_qtz_fan.py:452-530), device memory
+ *   index [B] image of each batch slot (NULL: slot b = image b)
+ *   off_y, off_x [B] crop offsets inside the zero-padded image, each 0..2*pad (NULL: pad = no shift)
+ *   flip  [B] nonzero: mirror horizontally after the crop (NULL: never)
+ *   mean, std: HOST arrays of C floats;  out [B, C, H, W] fp32 = (u8/255 - mean[c]) / std[c]
+ * Validation batches (ToTensor + Normalize only, :171-174) pass NULL offsets / flip.  The caller draws
+ * the random numbers. */
+int aq_augment_batch(const uint8_t *data, long long n_images, const int *index, const int *off_y,
+                     const int *off_x, const uint8_t *flip, int B, int H, int W, int C, int pad,
+                     const float *mean, const float *std, float *out, void *stream);
+
+/* max |v| of n tensors in one launch (per 32 tensors): the scales s the power-of-two variants derive
+ * from a trained full-precision model, `torch.max(torch.abs(param))` per conv / linear weight
+ * (adp_qtz_fix.py:208-213, adp_qtz_hint.py:204-209).  tensors, sizes: HOST arrays of n device
+ * pointers / element counts; out: device [n]. */
+int aq_absmax(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

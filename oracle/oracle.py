@@ -222,6 +222,28 @@ def unpack_codes(packed, n, bits):
     return np.packbits(full, axis=1, bitorder="little").reshape(-1)
 
 
+def augment_batch(data, index, off_y, off_x, flip, pad=4, mean=(0.4915, 0.4821, 0.4462), std=(0.2472, 0.2437, 0.2617)):
+    """torchvision's RandomCrop(H, padding=pad) + RandomHorizontalFlip + ToTensor + Normalize for given
+    random draws (adp_qtz_fan.py:164-169), image by image, in fp32: pad with zeros, crop, mirror,
+    u8/255, (v - mean)/std.  data (N, H, W, C) uint8 -> (B, C, H, W) float32."""
+    data = np.asarray(data, np.uint8)
+    N, H, W, Cn = data.shape
+    B = len(index)
+    out = np.empty((B, Cn, H, W), np.float32)
+    mean = np.asarray(mean, np.float32)[:Cn]
+    std = np.asarray(std, np.float32)[:Cn]
+    for b in range(B):
+        img = np.zeros((H + 2 * pad, W + 2 * pad, Cn), np.uint8)
+        img[pad:pad + H, pad:pad + W] = data[index[b]]
+        crop = img[off_y[b]:off_y[b] + H, off_x[b]:off_x[b] + W]
+        if flip[b]:
+            crop = crop[:, ::-1]
+        t = crop.astype(np.float32) / np.float32(255.0)
+        t = (t - mean) / std
+        out[b] = t.transpose(2, 0, 1)
+    return out
+
+
 def levels_fix(s, num_level, liar=True):
     """adp_qtz_fix.py:661-665: [-2^t .. descending magnitude], 0, [2^t ..]; num_level-1 entries."""
     import math

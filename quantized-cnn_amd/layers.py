@@ -452,11 +452,15 @@ def model_loss(config, beta, model):
 def scales_from_baseline(model_b):
     """max|W| of the 19 conv + 1 linear weights of a trained full-precision ResNet-20 and its
     linear bias (adp_qtz_fix.py:208-215, adp_qtz_hint.py:204-211)."""
-    s, v = [], None
+    ws, v = [], None
     for name, param in model_b.named_parameters():
         if ("conv" in name and "weight" in name) or ("linear" in name and "weight" in name):
-            s.append(torch.max(torch.abs(param)).item())
+            ws.append(param.detach())
         elif "linear" in name and "bias" in name:
             v = param
-    assert len(s) == 20
+    assert len(ws) == 20
+    if all(w.is_cuda and w.dtype == torch.float32 for w in ws):
+        s = ops.absmax([w.contiguous() for w in ws]).tolist()  # one launch, one read-back
+    else:
+        s = [torch.max(torch.abs(w)).item() for w in ws]  # a baseline still on the host (as loaded from disk)
     return s, v

@@ -356,3 +356,38 @@ def unpack_codes(packed, n, bits):
     idx = torch.empty(int(n), dtype=torch.uint8, device=packed.device)
     _lib.check(_lib.lib().aq_unpack_codes(_lib.ptr(packed, torch.uint8, "packed"), int(n), int(bits), _lib.ptr(idx, torch.uint8), _lib.stream()))
     return idx
+
+
+# --------------------------------------------------------------------- input pipeline, scales
+
+def augment_batch(data, index=None, off_y=None, off_x=None, flip=None, pad=4, mean=(0.4915, 0.4821, 0.4462),
+                  std=(0.2472, 0.2437, 0.2617), batch=None):
+    """Normalised NCHW fp32 batch from the raw uint8 image array (N, H, W, C): gather `index`, zero-pad by
+    `pad`, crop at (off_y, off_x) in 0..2*pad, mirror where `flip`, then ToTensor + Normalize
+    (adp_qtz_fan.py:164-174).  index / off_y / off_x: int32 device tensors [B]; flip: uint8 [B]; any of
+    them None = identity.  Defaults are the reference's constants."""
+    if data.dim() != 4 or data.dtype != torch.uint8:
+        raise ValueError("augment_batch: data must be uint8 (N, H, W, C)")
+    N, H, W, Cn = data.shape
+    B = int(batch if batch is not None else (index.numel() if index is not None else N))
+    for t, name in ((index, "index"), (off_y, "off_y"), (off_x, "off_x"), (flip, "flip")):
+        if t is not None and t.numel() != B:
+            raise ValueError("augment_batch: %s has %d entries for a batch of %d" % (name, t.numel(), B))
+    out = torch.empty((B, Cn, H, W), dtype=torch.float32, device=data.device)
+    m = (C.c_float * Cn)(*[float(v) for v in mean][:Cn])
+    sd = (C.c_float * Cn)(*[float(v) for v in std][:Cn])
+    _lib.check(_lib.lib().aq_augment_batch(
+        _lib.ptr(data, torch.uint8, "data"), int(N), _lib.ptr(index, torch.int32, "index"), _lib.ptr(off_y, torch.int32, "off_y"),
+        _lib.ptr(off_x, torch.int32, "off_x"), _lib.ptr(flip, torch.uint8, "flip"), B, int(H), int(W), int(Cn), int(pad), m, sd,
+        _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def absmax(tensors):
+    """max |v| of every tensor in the list, one launch per 32 tensors -> fp32 device tensor [n]."""
+    n = len(tensors)
+    out = torch.empty(n, dtype=torch.float32, device=tensors[0].device)
+    ptrs = (C.c_void_p * n)(*[_lib.ptr(t, name="tensor[%d]" % i) for i, t in enumerate(tensors)])
+    sizes = (C.c_longlong * n)(*[t.numel() for t in tensors])
+    _lib.check(_lib.lib().aq_absmax(ptrs, sizes, n, _lib.ptr(out), _lib.stream()))
+    return out

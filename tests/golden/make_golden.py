@@ -489,10 +489,53 @@ def gen_ckpt(torch):
     print("ckpt_fan.pt: %d bytes; losses %s -> %.6f" % (os.path.getsize(path), losses, l3))
 
 
+def gen_baseline(torch):
+    """The full-precision ResNet of adp_qtz_baseline.py (n=1 and n=3): logits, CE + model_loss, gradients
+    after one backward pass, one SGD(momentum 0.9) step, and the scales / bias the fix script derives
+    from such a model (adp_qtz_fix.py:208-215)."""
+    mod = load_ref("adp_qtz_baseline.py")
+    out = {}
+    for n in (1, 3):
+        rs = np.random.RandomState(70 + n)
+        model = mod.ResNet(n)
+        fill_model_from_numpy(torch, model, 21 + n)
+        model.train()
+        B = 4
+        x = torch.from_numpy(rs.standard_normal((B, 3, 32, 32)).astype(np.float32))
+        y = torch.from_numpy(rs.randint(0, 10, B).astype(np.int64))
+        c = argparse.Namespace(l2_reg=1e-4)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+        losses = []
+        k = "n%d_" % n
+        for it in range(3):
+            logits = model.forward(x)
+            loss = torch.nn.functional.cross_entropy(logits, y) + mod.model_loss(c, model)
+            loss.backward()
+            if it == 0:
+                named = dict(model.named_parameters())
+                out[k + "logits0"] = f32(logits.detach().numpy())
+                for name in ("conv0.weight", "layer2.0.conv1.weight", "layer3.0.conv2.weight", "linear.weight", "bn0.weight"):
+                    out[k + "g0_" + name] = f32(named[name].grad.numpy())
+            opt.step(); opt.zero_grad()
+            losses.append(loss.item())
+        sc, v = [], None
+        for name, param in model.named_parameters():
+            if ('conv' in name and 'weight' in name) or ('linear' in name and 'weight' in name):
+                sc.append(torch.max(torch.abs(param)).item())
+            elif 'linear' in name and 'bias' in name:
+                v = param
+        out[k + "x"] = f32(x.numpy()); out[k + "y"] = y.numpy(); out[k + "loss"] = np.array(losses)
+        out[k + "s"] = np.array(sc, np.float64); out[k + "v"] = f32(v.detach().numpy())
+        out[k + "keys"] = np.array(list(model.state_dict().keys()))
+        out[k + "p_sum"] = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
+        print("baseline n=%d losses %s, %d scales" % (n, losses, len(sc)))
+    np.savez_compressed(os.path.join(OUT, "baseline.npz"), **out)
+
+
 def main():
     import torch
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block", "ckpt"]
+    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block", "ckpt", "baseline"]
     for w in which:
         globals()["gen_" + w](torch)
 

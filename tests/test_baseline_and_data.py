@@ -1,0 +1,181 @@
+"""Full-precision baseline model (adp_qtz_baseline.py) and the device-side input pipeline."""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+
+def _fill(model, seed):
+    from test_gpu_model import fill_model_from_numpy
+    fill_model_from_numpy(model, seed, False)
+
+
+# ------------------------------------------------------------------------------------ CPU: reader
+
+def _fake_cifar(dirname, per_batch=10):
+    rs = np.random.RandomState(0)
+    allb = {}
+    for name in ["data_batch_%d" % i for i in range(1, 6)] + ["test_batch"]:
+        d = {b"data": rs.randint(0, 256, (per_batch, 3072)).astype(np.uint8), b"labels": [int(v) for v in rs.randint(0, 10, per_batch)],
+             b"batch_label": name.encode(), b"filenames": [b"f%d.png" % i for i in range(per_batch)]}
+        with open(os.path.join(dirname, name), "wb") as f:
+            pickle.dump(d, f)
+        allb[name] = d
+    return allb
+
+
+def test_cifar_reader_split_and_layout(tmp_path):
+    """Same split and layout as adp_qtz_fan.py:458-507 on a synthetic directory in the CIFAR-10 python format."""
+    from quantized_cnn_amd import data as D
+    b = _fake_cifar(str(tmp_path))
+    tr, ltr = D.load_data(str(tmp_path), "train")
+    va, lva = D.load_data(str(tmp_path), "valid")
+    te, lte = D.load_data(str(tmp_path), "test")
+    assert tr.shape == (45, 32, 32, 3) and va.shape == (5, 32, 32, 3) and te.shape == (10, 32, 32, 3)
+    assert tr.dtype == np.uint8 and ltr.dtype == np.int64
+    raw = b["data_batch_2"][b"data"][3]                      # rows are RRR..GGG..BBB.. planes
+    assert np.array_equal(tr[13], raw.reshape(3, 32, 32).transpose(1, 2, 0))
+    assert np.array_equal(tr[40:], b["data_batch_5"][b"data"][:5].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+    assert np.array_equal(va, b["data_batch_5"][b"data"][5:].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+    assert list(lva) == b["data_batch_5"][b"labels"][5:] and list(lte) == b["test_batch"][b"labels"]
+    with pytest.raises(ValueError):
+        D.load_data(str(tmp_path), "nope")
+
+
+def test_batch_files_cannot_smuggle_code(tmp_path):
+    from quantized_cnn_amd import data as D
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    with open(str(tmp_path / "x"), "wb") as f:
+        pickle.dump({b"data": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        D.unpickle(str(tmp_path / "x"))
+
+
+def test_oracle_augment_known_answers():
+    data = np.arange(2 * 4 * 4 * 3, dtype=np.uint8).reshape(2, 4, 4, 3)
+    mean, std = (0.5, 0.25, 0.0), (0.5, 1.0, 2.0)
+    out = O.augment_batch(data, [1, 0], [1, 0], [1, 2], [0, 1], pad=1, mean=mean, std=std)
+    # slot 0: image 1, offsets (1, 1) = no shift, no flip
+    want = (data[1].astype(np.float32) / np.float32(255) - np.float32(mean)) / np.float32(std)
+    assert np.array_equal(out[0], want.transpose(2, 0, 1))
+    # slot 1: image 0 shifted down by one row (off_y = 0), one column to the left (off_x = 2), mirrored
+    pad = np.zeros((6, 6, 3), np.uint8); pad[1:5, 1:5] = data[0]
+    crop = pad[0:4, 2:6][:, ::-1]
+    want = (crop.astype(np.float32) / np.float32(255) - np.float32(mean)) / np.float32(std)
+    assert np.array_equal(out[1], want.transpose(2, 0, 1))
+    assert out[1][0, 0, 0] == np.float32(-1.0)  # padding: (0 - 0.5) / 0.5
+
+
+# ------------------------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+def test_augment_kernel_bit_exact_vs_oracle():
+    import quantized_cnn_amd.ops as ops
+    rs = np.random.RandomState(3)
+    data = rs.randint(0, 256, (50, 32, 32, 3)).astype(np.uint8)
+    B = 37
+    idx = rs.randint(0, 50, B).astype(np.int32)
+    oy, ox = rs.randint(0, 9, B).astype(np.int32), rs.randint(0, 9, B).astype(np.int32)
+    oy[:4], ox[:4] = [0, 8, 0, 8], [0, 0, 8, 8]
+    flip = rs.randint(0, 2, B).astype(np.uint8)
+    d = torch.from_numpy(data).cuda()
+    got = ops.augment_batch(d, torch.from_numpy(idx).cuda(), torch.from_numpy(oy).cuda(), torch.from_numpy(ox).cuda(), torch.from_numpy(flip).cuda())
+    want = O.augment_batch(data, idx, oy, ox, flip)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # validation transform: no shift, no mirror, slot b = image b
+    got = ops.augment_batch(d)
+    want = O.augment_batch(data, np.arange(50), np.full(50, 4), np.full(50, 4), np.zeros(50))
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # other geometry: one channel, odd size, pad 2
+    data = rs.randint(0, 256, (5, 7, 9, 1)).astype(np.uint8)
+    idx = np.array([4, 4, 0], np.int32); oy = np.array([0, 4, 2], np.int32); ox = np.array([4, 0, 1], np.int32); flip = np.array([1, 0, 1], np.uint8)
+    got = ops.augment_batch(torch.from_numpy(data).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(oy).cuda(), torch.from_numpy(ox).cuda(),
+                            torch.from_numpy(flip).cuda(), pad=2, mean=(0.3,), std=(0.7,))
+    assert np.array_equal(got.cpu().numpy(), O.augment_batch(data, idx, oy, ox, flip, 2, (0.3,), (0.7,)))
+
+
+@pytest.mark.gpu
+def test_gpu_loader_epochs():
+    from quantized_cnn_amd.data import GpuLoader
+    rs = np.random.RandomState(1)
+    data = rs.randint(0, 256, (70, 32, 32, 3)).astype(np.uint8)
+    label = np.arange(70) % 10
+    tr = GpuLoader(data, label, 32, train=True, seed=5)
+    assert len(tr) == 3
+    seen, shapes = [], []
+    for x, y in tr:
+        assert x.dtype == torch.float32 and x.is_cuda and y.dtype == torch.int64
+        shapes.append(tuple(x.shape))
+        seen.append(y)
+    assert shapes == [(32, 3, 32, 32), (32, 3, 32, 32), (6, 3, 32, 32)]
+    assert sorted(torch.cat(seen).tolist()) == sorted(label.tolist())     # a permutation: every image once
+    first = [y.clone() for _, y in GpuLoader(data, label, 32, train=True, seed=5)]
+    assert all(torch.equal(a, b) for a, b in zip(first, seen))            # seeded: reproducible
+    va = GpuLoader(data, label, 100, train=False)
+    (x, y), = list(va)
+    assert torch.equal(y.cpu(), torch.from_numpy(label))
+    want = O.augment_batch(data, np.arange(70), np.full(70, 4), np.full(70, 4), np.zeros(70))
+    assert np.array_equal(x.cpu().numpy(), want)
+    # crop statistics: offsets uniform over 0..8, about half the images mirrored
+    big = GpuLoader(np.zeros((4000, 32, 32, 3), np.uint8) + 255, np.zeros(4000), 4000, train=True, seed=0)
+    (x, _), = list(big)
+    border_rows = (x[:, 0, :, 16] < 0).sum(dim=1).float()                  # padded rows visible per image
+    assert abs(border_rows.mean().item() - 20.0 / 9.0) < 0.15              # E|off-4| = 20/9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3])
+def test_baseline_model_matches_reference(golden, n):
+    """Logits, gradients, three SGD steps and the derived scales against the reference's baseline ResNet
+    (fp32 both sides; 3e-5 of each tensor's scale, loss curve 1e-4)."""
+    import quantized_cnn_amd.adp_qtz_baseline as base
+    from quantized_cnn_amd.layers import scales_from_baseline
+    g = golden("baseline")
+    k = "n%d_" % n
+    model = base.ResNet(n)
+    assert list(model.state_dict().keys()) == list(g[k + "keys"])
+    _fill(model, 21 + n)
+    model = model.cuda().train()
+    x, y = torch.from_numpy(g[k + "x"]).cuda(), torch.from_numpy(g[k + "y"]).cuda()
+    c = argparse.Namespace(l2_reg=1e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    losses = []
+    for it in range(3):
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits, y) + base.model_loss(c, model)
+        loss.backward()
+        if it == 0:
+            named = dict(model.named_parameters())
+            assert np.abs(logits.detach().cpu().numpy() - g[k + "logits0"]).max() <= 3e-5 * np.abs(g[k + "logits0"]).max()
+            for name in ("conv0.weight", "layer2.0.conv1.weight", "layer3.0.conv2.weight", "linear.weight", "bn0.weight"):
+                ref = g[k + "g0_" + name]
+                assert np.abs(named[name].grad.cpu().numpy() - ref).max() <= 3e-5 * np.abs(ref).max(), name
+        opt.step(); opt.zero_grad()
+        losses.append(loss.item())
+    assert np.abs(np.array(losses) - g[k + "loss"]).max() <= 1e-4 * g[k + "loss"].max(), (losses, g[k + "loss"])
+    sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
+    assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+    if n == 3:
+        s, v = scales_from_baseline(model)
+        assert np.allclose(s, g[k + "s"], rtol=1e-4) and np.allclose(v.detach().cpu().numpy(), g[k + "v"], atol=1e-5)
+        # exact maxima of what is in memory
+        want = [float(p.detach().abs().max()) for nme, p in model.named_parameters()
+                if ("conv" in nme and "weight" in nme) or ("linear" in nme and "weight" in nme)]
+        assert s == want
+
+
+@pytest.mark.gpu
+def test_absmax_many_tensors():
+    import quantized_cnn_amd.ops as ops
+    torch.manual_seed(0)
+    ts = [torch.randn(n, device="cuda") * (i + 1) for i, n in enumerate([1, 5, 255, 256, 257, 36864] * 7)]
+    got = ops.absmax(ts)
+    assert got.tolist() == [float(t.abs().max()) for t in ts]
