@@ -152,6 +152,18 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
                    const float *save_mean, const float *save_rstd, const float *res, int N, int C, int HW,
                    unsigned flags, float *dx, float *dgamma, float *dbeta, void *workspace,
                    size_t workspace_bytes, void *stream);
+/* The network's tail `out = F.relu(self.bnlast(out)); out = self.ap(out)` (adp_qtz_fan.py:730-731, ap =
+ * nn.AvgPool2d(8) on an 8x8 map, i.e. the mean over the plane) in one step: pooled[N, C] = mean over
+ * H*W of [relu](batch_norm(x)); the activated tensor is never written.  Other arguments as
+ * aq_bn_relu_fwd.  aq_bn_relu_pool_bwd takes d loss / d pooled [N, C] and returns dx, dgamma, dbeta. */
+int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                        float *running_var, long long *num_batches_tracked, int N, int C, int HW, float eps,
+                        float momentum, unsigned flags, float *pooled, float *save_mean, float *save_rstd,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta,
+                        const float *save_mean, const float *save_rstd, int N, int C, int HW, unsigned flags,
+                        float *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                        void *stream);
 size_t aq_bn_workspace_bytes(int N, int C, int HW);
 
 /* Shortcut of the dimension-increasing blocks, nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0,

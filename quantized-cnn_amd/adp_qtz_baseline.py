@@ -80,8 +80,7 @@ class ResNet(nn.Module):
             raise RuntimeError("this ResNet runs on the HIP device only (input is on %s)" % x.device)
         out = layers.bn_relu(self.bn0, _conv(self.conv0, x))
         out = self.layer3(self.layer2(self.layer1(out)))
-        out = layers.bn_relu(self.bnlast, out)
-        out = self.ap(out)
+        out = layers.bn_relu_pool(self.bnlast, self.ap, out)
         out = out.view(out.size(0), -1)
         return self.linear(out)
 

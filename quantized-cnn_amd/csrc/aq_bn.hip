@@ -88,7 +88,7 @@ __device__ inline void for_slice(int n0, int n1, int c, int C, int HW, F f)
     const int total = (n1 - n0) * per;
     for (int i = threadIdx.x; i < total; i += BN_T) {
         const int n = i / per, k = i - n * per;
-        f(((size_t)(n0 + n) * C + c) * HW + (size_t)k * VEC);
+        f(((size_t)(n0 + n) * C + c) * HW + (size_t)k * VEC, n0 + n);
     }
 }
 
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict_
     const int n0 = s * g.npb, n1 = min(g.N, n0 + g.npb);
     const float cnt = (float)(n1 - n0) * (float)g.HW;
     float a = 0.0f;
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int) {
         auto v = Vec<VEC>::load(x + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) a += v[j];
     });
     const float mean = block_sum(a, sh) / cnt;
     float m2 = 0.0f;
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int) {
         auto v = Vec<VEC>::load(x + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -131,11 +131,10 @@ struct BnApplyArgs {
     int eval;
 };
 
-template <int VEC, bool RELU>
-__global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
+// first wavefront of a block: channel statistics -> sc[0] = scale, sc[1] = shift; block 0 of the channel
+// also stores them for the backward pass and updates the running statistics
+__device__ inline void bn_finalize(const BnApplyArgs &a, const BnGeom &g, int c, float *sc)
 {
-    __shared__ float sc[2];
-    const int c = blockIdx.y;
     if (threadIdx.x < 64) {
         float mean, rstd;
         if (a.eval) {
@@ -167,9 +166,17 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
         if (threadIdx.x == 0) scale_shift(a.gamma[c], a.beta[c], mean, rstd, sc[0], sc[1]);
     }
     __syncthreads();
+}
+
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
+{
+    __shared__ float sc[2];
+    const int c = blockIdx.y;
+    bn_finalize(a, g, c, sc);
     const float scale = sc[0], shift = sc[1];
     const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int) {
         auto v = Vec<VEC>::load(a.x + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -180,7 +187,30 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
     });
 }
 
+// normalisation + ReLU + mean over the plane (the network's tail: relu(bnlast(x)) followed by an
+// average pool over the whole 8x8 map, adp_qtz_fan.py:730-731) without writing the activated tensor:
+// one wavefront per (image, channel), a.y receives [N, C] means.
+template <bool RELU>
+__global__ __launch_bounds__(BN_T) void bn_apply_pool_kernel(BnApplyArgs a, BnGeom g)
+{
+    __shared__ float sc[2];
+    const int c = blockIdx.y;
+    bn_finalize(a, g, c, sc);
+    const float scale = sc[0], shift = sc[1];
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= g.N) return;
+    const float *p = a.x + ((size_t)n * g.C + c) * g.HW;
+    float acc = 0.0f;
+    for (int i = lane; i < g.HW; i += 64) {
+        const float t = __builtin_fmaf(p[i], scale, shift);
+        acc += RELU ? fmaxf(t, 0.0f) : t;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.y[(size_t)n * g.C + c] = acc / (float)g.HW;
+}
+
 struct BnBwdArgs {
+    const float *dpool;  // when set: d loss / d pooled [N, C]; the gradient of every element of plane (n, c) is dpool[n, c] / HW
     const float *dy, *x, *res;
     float *dx;
     float2 *part;
@@ -198,8 +228,16 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(BnBwdArgs a, BnGeom
     float scale, shift;
     scale_shift(a.gamma[c], a.beta[c], mean, rstd, scale, shift);
     float s1 = 0.0f, s2 = 0.0f;
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
-        auto d = Vec<VEC>::load(a.dy + o);
+    const float inv_hw = 1.0f / (float)g.HW;
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int n) {
+        Vec<VEC> d;
+        if (a.dpool) {
+            const float t = a.dpool[(size_t)n * g.C + c] * inv_hw;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) d[j] = t;
+        } else {
+            d = Vec<VEC>::load(a.dy + o);
+        }
         auto v = Vec<VEC>::load(a.x + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -239,8 +277,16 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
     float scale, shift;
     scale_shift(a.gamma[c], a.beta[c], mean, rstd, scale, shift);
     const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o) {
-        auto d = Vec<VEC>::load(a.dy + o);
+    const float inv_hw = 1.0f / (float)g.HW;
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int n) {
+        Vec<VEC> d;
+        if (a.dpool) {
+            const float t = a.dpool[(size_t)n * g.C + c] * inv_hw;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) d[j] = t;
+        } else {
+            d = Vec<VEC>::load(a.dy + o);
+        }
         auto v = Vec<VEC>::load(a.x + o);
         Vec<VEC> r;
         if (RES) r = Vec<VEC>::load(a.res + o);
@@ -279,9 +325,9 @@ size_t aq_bn_workspace_bytes(int N, int C, int HW)
     return (size_t)C * g.S * sizeof(float2);
 }
 
-int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
-                   long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
-                   float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                       long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
+                       float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream, bool pool)
 {
     using namespace aq;
     const bool eval = flags & AQ_BN_EVAL, relu = flags & AQ_BN_RELU;
@@ -305,6 +351,12 @@ int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float 
     BnApplyArgs a{x, y, static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
                   save_mean, save_rstd, eps, momentum, eval ? 1 : 0};
     const dim3 grid(g.S2, C);
+    if (pool) {
+        const dim3 pgrid((N + 3) / 4, C);
+        if (relu) hipLaunchKernelGGL((bn_apply_pool_kernel<true>), pgrid, dim3(BN_T), 0, st, a, g);
+        else hipLaunchKernelGGL((bn_apply_pool_kernel<false>), pgrid, dim3(BN_T), 0, st, a, g);
+        return check_launch("aq_bn_relu_pool_fwd");
+    }
     if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true>), grid, dim3(BN_T), 0, st, a, g);
     else if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, false>), grid, dim3(BN_T), 0, st, a, g);
     else if (relu) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, dim3(BN_T), 0, st, a, g);
@@ -312,21 +364,37 @@ int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float 
     return check_launch("aq_bn_relu_fwd");
 }
 
-int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
-                   const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma,
-                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream)
+int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                   long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
+                   float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, flags, y, save_mean, save_rstd,
+                       workspace, workspace_bytes, stream, false);
+}
+
+int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *pooled,
+                        float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, flags, pooled, save_mean,
+                       save_rstd, workspace, workspace_bytes, stream, true);
+}
+
+static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, const float *gamma, const float *beta, const float *save_mean,
+                       const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma, float *dbeta,
+                       void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace aq;
     if (int rc = check_dims("aq_bn_relu_bwd", N, C, HW, true)) return rc;
-    AQ_REQUIRE(dy && x && gamma && beta && save_mean && save_rstd && dx, -EFAULT, "aq_bn_relu_bwd: NULL pointer");
+    AQ_REQUIRE((dy || dpool) && x && gamma && beta && save_mean && save_rstd && dx, -EFAULT, "aq_bn_relu_bwd: NULL pointer");
     AQ_REQUIRE((flags & ~AQ_BN_RELU) == 0, -EINVAL, "aq_bn_relu_bwd: unsupported flags 0x%x (batch-statistics mode only)", flags);
     const BnGeom g = bn_geom(N, C, HW);
     AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_bwd: workspace of %zu bytes needed, %zu given",
                (size_t)C * g.S * sizeof(float2), workspace_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool relu = flags & AQ_BN_RELU;
-    const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && (!res || aligned16(res));
-    BnBwdArgs a{dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta};
+    const bool vec = HW % 4 == 0 && aligned16(x) && (!dy || aligned16(dy)) && aligned16(dx) && (!res || aligned16(res));
+    BnBwdArgs a{dpool, dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta};
     const dim3 g1(g.S, C), g2(g.S2, C);
 #define AQ_BN_BWD(V, R)                                                                                        \
     {                                                                                                          \
@@ -340,6 +408,24 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
     else AQ_BN_BWD(1, false)
 #undef AQ_BN_BWD
     return check_launch("aq_bn_relu_bwd");
+}
+
+int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
+                   const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma,
+                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AQ_REQUIRE(dy, -EFAULT, "aq_bn_relu_bwd: NULL dy");
+    return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, res, N, C, HW, flags, dx, dgamma, dbeta, workspace, workspace_bytes,
+                       stream);
+}
+
+int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta, const float *save_mean,
+                        const float *save_rstd, int N, int C, int HW, unsigned flags, float *dx, float *dgamma, float *dbeta,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    AQ_REQUIRE(dpooled, -EFAULT, "aq_bn_relu_pool_bwd: NULL dpooled");
+    return bn_bwd_impl(nullptr, dpooled, x, gamma, beta, save_mean, save_rstd, nullptr, N, C, HW, flags, dx, dgamma, dbeta, workspace,
+                       workspace_bytes, stream);
 }
 
 } // extern "C"

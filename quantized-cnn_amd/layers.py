@@ -124,9 +124,10 @@ class _Conv3x3(torch.autograd.Function):
         dW = None
         if ctx.needs_input_grad[1]:
             if _wgrad_deferred is not None and ctx.dW_slot is not None:
+                # the gradient lands in the slot at the batched reduction; nothing is handed to autograd
+                # (it would clone the slot into the leaf's .grad)
                 ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
                 _wgrad_deferred.append((ws, ctx.dW_slot, nslab))
-                dW = ctx.dW_slot
             else:
                 dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot)
         return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None)
@@ -138,22 +139,38 @@ class _BnRelu(torch.autograd.Function):
     the backward kernel instead of by a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, relu, split):
+    def forward(ctx, x, gamma, beta, bn, relu, split, pool=False):
         x = x.contiguous()
         z, mean, rstd = ops.bn_relu_forward(x, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                                            bn.momentum, relu=relu)
+                                            bn.momentum, relu=relu, pool=pool)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.relu = relu
+        ctx.relu, ctx.pool = relu, pool
         return (z, x.view_as(x)) if split else z
 
     @staticmethod
     def backward(ctx, dz, dres=None):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dz is None:
-            dz = torch.zeros_like(x)
+            dz = torch.zeros((x.shape[0], x.shape[1]) if ctx.pool else x.shape, dtype=x.dtype, device=x.device)
         dx, dg, db = ops.bn_relu_backward(dz.contiguous(), x, gamma, beta, mean, rstd, res=dres.contiguous() if dres is not None else None,
-                                          relu=ctx.relu)
-        return dx, dg, db, None, None, None
+                                          relu=ctx.relu, pool=ctx.pool)
+        return dx, dg, db, None, None, None, None
+
+
+def bn_relu_pool(bn, pool, x):
+    """`out = F.relu(bn(x)); out = pool(out)` (adp_qtz_fan.py:730-731) -> (N, C, 1, 1).  When the pool is
+    an average over the whole plane (nn.AvgPool2d(8) on the 8x8 map of ResNet-20) the pair runs as one
+    fused kernel that never writes the activated tensor."""
+    ks = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size, pool.kernel_size)
+    whole = (isinstance(pool, nn.AvgPool2d) and x.dim() == 4 and tuple(ks) == tuple(x.shape[2:]) and pool.padding in (0, (0, 0))
+             and x.is_cuda and x.dtype == torch.float32 and bn.weight is not None)
+    if whole and (bn.training or bn.running_mean is None) and bn.momentum is not None:
+        return _BnRelu.apply(x, bn.weight, bn.bias, bn, True, False, True).view(x.shape[0], x.shape[1], 1, 1)
+    if whole and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
+        y = ops.bn_relu_forward(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps, 0.0, relu=True,
+                                use_running_stats=True, pool=True)[0]
+        return y.view(x.shape[0], x.shape[1], 1, 1)
+    return pool(bn_relu(bn, x))
 
 
 class _Shortcut(torch.autograd.Function):
@@ -203,10 +220,9 @@ class _LinearIO(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        dx, dW, db = ops.linear_backward(x, W.contiguous(), dy.contiguous(), need_dx=ctx.needs_input_grad[0])
-        if ctx.dW_slot is not None:
-            ctx.dW_slot.copy_(dW)
-            dW = ctx.dW_slot
+        dx, dW, db = ops.linear_backward(x, W.contiguous(), dy.contiguous(), need_dx=ctx.needs_input_grad[0], out_dW=ctx.dW_slot)
+        if _wgrad_deferred is not None and ctx.dW_slot is not None:
+            dW = None  # the owner of the deferred list reads the slot itself
         return dx, dW, db, None
 
 
@@ -415,8 +431,7 @@ class QResNet(nn.Module):
         out = self.layer1(out)
         out = self.layer2(out)
         out = self.layer3(out)
-        out = bn_relu(self.bnlast, out)
-        out = self.ap(out)
+        out = bn_relu_pool(self.bnlast, self.ap, out)
         out = out.view(out.size(0), -1)
         out = self.linear(out)
         return out

@@ -252,11 +252,13 @@ def linear_forward(x, W, bias):
     return y
 
 
-def linear_backward(x, W, dy, need_dx=True):
+def linear_backward(x, W, dy, need_dx=True, out_dW=None):
     N, In = x.shape
     Out = W.shape[1]
     dx = torch.empty_like(x) if need_dx else None
-    dW = torch.empty_like(W)
+    if out_dW is not None and (tuple(out_dW.shape) != tuple(W.shape) or not out_dW.is_contiguous()):
+        raise ValueError("linear_backward: out_dW must be contiguous with the shape of W %s" % (tuple(W.shape),))
+    dW = out_dW if out_dW is not None else torch.empty_like(W)
     db = torch.empty(Out, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().aq_linear_bwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(dy, name="dy"), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db),
                                         N, In, Out, _lib.stream()))
@@ -273,12 +275,14 @@ def _bn_dims(x):
 
 
 def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1,
-                    relu=True, use_running_stats=False):
+                    relu=True, use_running_stats=False, pool=False):
     """y = [relu](batch_norm(x)) over (N, H, W) of an NCHW tensor (adp_qtz_fan.py:674-675, 690, 726, 730).
     Batch-statistics mode returns (y, save_mean, save_rstd) and updates the running statistics in
-    place like nn.BatchNorm2d in training mode; use_running_stats=True normalises with them instead."""
+    place like nn.BatchNorm2d in training mode; use_running_stats=True normalises with them instead.
+    pool=True returns the mean of y over each (image, channel) plane, shape (N, C), instead of y (the
+    network's tail, adp_qtz_fan.py:730-731)."""
     N, Cn, HW = _bn_dims(x)
-    y = torch.empty_like(x)
+    y = torch.empty((N, Cn), dtype=torch.float32, device=x.device) if pool else torch.empty_like(x)
     flags = (_lib.BN_RELU if relu else 0) | (_lib.BN_EVAL if use_running_stats else 0)
     mean = rstd = ws = None
     nbytes = 0
@@ -287,7 +291,8 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
         rstd = torch.empty(Cn, dtype=torch.float32, device=x.device)
         nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.lib().aq_bn_relu_fwd(
+    fn = _lib.lib().aq_bn_relu_pool_fwd if pool else _lib.lib().aq_bn_relu_fwd
+    _lib.check(fn(
         _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
         _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), N, Cn, HW,
         float(eps), float(momentum), flags, _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), ws.data_ptr() if ws is not None else None, nbytes,
@@ -295,16 +300,26 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
     return y, mean, rstd
 
 
-def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True):
-    """-> (dx [+ res], dgamma, dbeta) of bn_relu_forward in batch-statistics mode."""
+def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True, pool=False):
+    """-> (dx [+ res], dgamma, dbeta) of bn_relu_forward in batch-statistics mode.  pool=True: dy is the
+    gradient of the pooled output, shape (N, C)."""
     N, Cn, HW = _bn_dims(x)
-    if dy.shape != x.shape or (res is not None and res.shape != x.shape):
+    if pool:
+        if tuple(dy.shape) != (N, Cn) or res is not None:
+            raise ValueError("bn_relu_backward(pool): dy must be (N, C) = (%d, %d) and res None" % (N, Cn))
+    elif dy.shape != x.shape or (res is not None and res.shape != x.shape):
         raise ValueError("bn_relu_backward: dy / res must have the shape of x %s" % (tuple(x.shape),))
     dx = torch.empty_like(x)
     dg = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
     db = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
     nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    if pool:
+        _lib.check(_lib.lib().aq_bn_relu_pool_bwd(
+            _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
+            _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), N, Cn, HW,
+            _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), ws.data_ptr(), nbytes, _lib.stream()))
+        return dx, dg, db
     _lib.check(_lib.lib().aq_bn_relu_bwd(
         _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
         _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(res, name="res"), N, Cn, HW,

@@ -465,3 +465,32 @@ def test_synth_backward_adam_argument_errors():
         ops.synth_backward_adam([p], [q], 1.0, [None], [torch.zeros(8, 31, device=DEV)], [torch.zeros_like(p)], [torch.zeros((), device=DEV)], 1e-2)
     with pytest.raises(RuntimeError, match="out of range"):
         ops.synth_backward_adam([p], [q], 1.0, [None], [torch.zeros_like(p)], [torch.zeros_like(p)], [torch.zeros((), device=DEV)], 1e-2, betas=(1.5, 0.9))
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 8, 8), (5, 3, 4, 4), (2, 7, 1, 1), (3, 2, 13, 11)])
+def test_bn_relu_with_fused_mean_pool(shape):
+    """relu(bn(x)) followed by the mean over the plane, fused: equals the unfused kernels to 1e-6 of
+    scale (other summation order), backward included."""
+    rs = np.random.RandomState(sum(shape))
+    N, Cn = shape[0], shape[1]
+    x = cu(rs.standard_normal(shape) * 1.7 + 0.4)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(Cn)), cu(0.3 * rs.standard_normal(Cn))
+    rm, rv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y, mean, rstd = ops.bn_relu_forward(x, g, b, rm, rv, None)
+    pooled, mean2, rstd2 = ops.bn_relu_forward(x, g, b, rm2, rv2, None, pool=True)
+    assert pooled.shape == (N, Cn)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    want = y.double().mean(dim=(2, 3))
+    assert (pooled.double() - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    dpool = cu(rs.standard_normal((N, Cn)))
+    HW = shape[2] * shape[3]
+    dy = (dpool / HW).view(N, Cn, 1, 1).expand(shape).contiguous()
+    dx1, dg1, db1 = ops.bn_relu_backward(dy, x, g, b, mean, rstd)
+    dx2, dg2, db2 = ops.bn_relu_backward(dpool, x, g, b, mean, rstd, pool=True)
+    assert (dx1 - dx2).abs().max().item() <= 1e-6 * max(1.0, dx1.abs().max().item())
+    assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-6) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-6)
+    # running-statistics mode
+    pe = ops.bn_relu_forward(x, g, b, rm, rv, None, use_running_stats=True, pool=True)[0]
+    ye = ops.bn_relu_forward(x, g, b, rm, rv, None, use_running_stats=True)[0]
+    assert (pe.double() - ye.double().mean(dim=(2, 3))).abs().max().item() <= 1e-6 * max(1.0, ye.abs().max().item())
