@@ -37,12 +37,19 @@ def set_dW_reduce_hook(fn):
 # (train.FusedTrainStep) reduces all of them with one launch after backward.  The slots hold no valid
 # gradient until then, so this is only for callers that read them afterwards.
 _wgrad_deferred = None
+# With deferral on, an optional second HIP stream for those first-stage kernels: the weight gradient
+# of a layer depends only on (x, dy), nothing in the rest of the backward pass depends on it, and both it
+# and the input-gradient kernel are latency-bound, so they overlap almost completely.  The owner joins the
+# stream before reducing; the job entries keep x and dy alive until then.
+_wgrad_stream = None
 
 
-def defer_wgrad_reductions(jobs):
-    """jobs: a list to collect into, or None to switch deferral off.  Returns the previous setting."""
-    global _wgrad_deferred
-    prev, _wgrad_deferred = _wgrad_deferred, jobs
+def defer_wgrad_reductions(jobs, stream=None):
+    """jobs: a list to collect into, or None to switch deferral off; stream: side stream for the deferred
+    kernels (None: the current stream).  Returns the previous (jobs, stream) setting."""
+    global _wgrad_deferred, _wgrad_stream
+    prev = (_wgrad_deferred, _wgrad_stream)
+    _wgrad_deferred, _wgrad_stream = jobs, (stream if jobs is not None else None)
     return prev
 
 
@@ -126,8 +133,13 @@ class _Conv3x3(torch.autograd.Function):
             if _wgrad_deferred is not None and ctx.dW_slot is not None:
                 # the gradient lands in the slot at the batched reduction; nothing is handed to autograd
                 # (it would clone the slot into the leaf's .grad)
-                ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
-                _wgrad_deferred.append((ws, ctx.dW_slot, nslab))
+                if _wgrad_stream is not None:
+                    _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
+                    with torch.cuda.stream(_wgrad_stream):
+                        ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
+                else:
+                    ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
+                _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
             else:
                 dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot)
         return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None)

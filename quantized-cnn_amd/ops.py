@@ -233,7 +233,7 @@ def conv_wgrad_reduce(jobs):
     if not jobs:
         return
     arr = (_lib.AqWgradJob * len(jobs))()
-    for j, (ws, dW, nslab) in enumerate(jobs):
+    for j, (ws, dW, nslab) in enumerate(job[:3] for job in jobs):
         arr[j].part, arr[j].dW = ws.data_ptr(), _lib.ptr(dW, name="dW")
         arr[j].n, arr[j].nslab = dW.numel(), nslab
     _lib.check(_lib.lib().aq_conv_wgrad_reduce(arr, len(jobs), _lib.stream()))
