@@ -29,7 +29,40 @@ namespace aq {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#ifdef AQ_EXPERIMENT
+// experiment builds: per-phase timestamps (100 MHz wall clock) of three workgroups (first, middle, last)
+// and two threads each (0 and 256), 16 slots per (workgroup, thread)
+__device__ long long aq_trace[3 * 2 * 16];
+#define AQ_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.z == 0) {                \
+            const int w_ = blockIdx.x == 0 ? 0 : ((blockIdx.x == gridDim.x / 2) ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1)); \
+            if (w_ >= 0) aq_trace[(w_ * 2 + (threadIdx.x >> 8)) * 16 + (i)] = wall_clock64();                \
+        }                                                                                                    \
+    } while (0)
+#else
+#define AQ_STAMP(i) do { } while (0)
+#endif
+
 enum ConvMode { MODE_FWD = 0, MODE_FWD_CODES = 1, MODE_DGRAD = 2 };
+
+// Buffer addressing (raw buffer resource: base pointer + size in bytes): a lane's 32-bit byte offset is
+// range-checked by the hardware, loads beyond the size return 0 and stores are dropped, so a predicate
+// costs one select on the offset instead of a branch around the access, and per-channel / per-image
+// strides ride in the scalar offset.  BUF_OOB is an offset no tensor reaches (sizes are < 2 GiB here).
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
 
 struct ConvArgs {
     const float *in;     // x (forward) or dy (dgrad), NCHW
@@ -274,7 +307,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
 // of the current tile run, and the main loop touches only LDS, so those loads stay in flight.
 // CH4 = input channels per wavefront, J = plane elements per lane.
 template <int MT, int NT, int CH4, int J, int MODE>
-__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift)
+__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift,
+                                                                const unsigned k4n_rcp)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *ktab = reinterpret_cast<int *>(smem);       // [Kpad]
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jn = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 16 * MT;
+    AQ_STAMP(0);
 
     for (int k = tid; k < a.Kpad; k += 256) {
         int off = 0;
@@ -319,13 +354,14 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
         pyx[t] = px < a.OW ? ((py << 16) | px) : -1;
     }
     const int chs = a.IH * a.IW;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // wavefront index as a scalar
 
     float sv[CH4][J];
     auto fetch_tile = [&](int tile) {
         const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
         const int r0 = ty * a.TH * a.rs - 1;
-        const float *__restrict__ src = a.in + (long long)n * a.KC * chs;
-        int off[J];
+        const __amdgpu_buffer_rsrc_t src = make_rsrc(a.in + (long long)n * a.KC * chs, (unsigned)(a.KC * chs) * 4u);
+        unsigned off[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             int gy = r0 + rj[j];
@@ -335,16 +371,18 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                 gy >>= 1;
             }
             ok = ok && gy < a.IH;
-            off[j] = ok ? gy * a.IW + gxj[j] : -1;
+            off[j] = ok ? (unsigned)(gy * a.IW + gxj[j]) * 4u : BUF_OOB;
         }
 #ifdef AQ_EXPERIMENT
         if (a.dbg & 2) return;
 #endif
 #pragma unroll
         for (int u = 0; u < CH4; ++u) {
-            const int c = wave + 4 * u;
+            // channels beyond KC are never committed: clamp so that the scalar offset stays inside the tensor
+            const int c = min(wave_s + 4 * u, a.KC - 1);
+            const unsigned soff = (unsigned)(c * chs) * 4u;
 #pragma unroll
-            for (int j = 0; j < J; ++j) sv[u][j] = (c < a.KC && off[j] >= 0) ? src[(long long)c * chs + off[j]] : 0.0f;
+            for (int j = 0; j < J; ++j) sv[u][j] = buf_load(src, off[j], soff);
         }
     };
     auto commit_tile = [&]() {
@@ -360,53 +398,78 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
     // the first tile's loads are issued before the weight panel's, so both are in flight together
     int tile = blockIdx.x;
     if (tile < ntiles) fetch_tile(tile);
+    AQ_STAMP(1);
 
     // weight panel in fragment order: element (row rl, k) lives at
     //   As[(((k>>4)*MT + (rl>>4))*64 + ((k>>2)&3)*16 + (rl&15))*4 + (k&3)]
-    // so the 4 consecutive k of one row form one 16-byte LDS store.  Work item = (row, group of 4 k);
-    // eight items per thread are loaded before the first store (the fill is latency-bound).
-    {
-        const int k4n = a.Kpad >> 2, items = 16 * MT * k4n;
-        for (int base = 0; base < items; base += 256 * 8) {
-            float4 w[8];
+    // so the 4 consecutive k of one row form one 16-byte LDS store.  Forward: work item = (row, group of
+    // 4 k); all items of a thread are loaded before the first store (the fill is latency-bound).
+    auto as_index = [&](int rl, int k) { return (((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4 + (k & 3); };
+    if (MODE == MODE_DGRAD) {
+        // A[row = ci, k = (co, tap)] = W[co, ci, 8 - tap]: work item = (co, row), whose nine taps are
+        // contiguous in memory; all loads of a round are issued before the first LDS store
+        const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(a.W, (unsigned)(a.Cout * a.Cin * 9) * 4u);
+        const int items = 16 * MT * a.KC;
+        for (int base = 0; base < items; base += 256 * 4) {
+            float w[4][9];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int it = base + u * 256 + tid;
-                const int rl = it / k4n, k = (it - rl * k4n) * 4;
+                const int c = it / (16 * MT), rl = it - c * (16 * MT);
+                const int row = m0 + rl;
+                const unsigned o = (it < items && row < a.M) ? (unsigned)((c * a.Cin + row) * 9) * 4u : BUF_OOB;
+#pragma unroll
+                for (int tw = 0; tw < 9; ++tw) w[u][tw] = buf_load(wsrc, o + 4u * tw, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = base + u * 256 + tid;
+                const int c = it / (16 * MT), rl = it - c * (16 * MT);
+                if (it < items) {
+#pragma unroll
+                    for (int tw = 0; tw < 9; ++tw) As[as_index(rl, c * 9 + 8 - tw)] = w[u][tw];
+                }
+            }
+        }
+        const int padk = a.Kpad - a.K;  // zero weights for the padded k
+        for (int it = tid; it < 16 * MT * padk; it += 256) {
+            const int rl = it / padk, k = a.K + it - rl * padk;
+            As[as_index(rl, k)] = 0.0f;
+        }
+    } else {
+        constexpr int PW = 10;  // items per thread and round: one round covers the ResNet-20 panels
+        const int k4n = a.Kpad >> 2, items = 16 * MT * k4n;
+        const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(a.W, (MODE == MODE_FWD && a.vecA) ? (unsigned)(a.M * a.K) * 4u : 0u);
+        for (int base = 0; base < items; base += 256 * PW) {
+            float4 w[PW];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                const int it = base + u * 256 + tid;
+                const int rl = (int)__umulhi((unsigned)it, k4n_rcp), k = (it - rl * k4n) * 4;
                 const int row = m0 + rl;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (it < items && row < a.M && k < a.K) {
-                    if (MODE == MODE_FWD && a.vecA) {
-                        v = *reinterpret_cast<const float4 *>(&a.W[(long long)row * a.K + k]);
-                    } else {
-                        float e[4];
+                if (MODE == MODE_FWD && a.vecA) {
+                    const unsigned o = (it < items && row < a.M && k < a.K) ? (unsigned)(row * a.K + k) * 4u : BUF_OOB;
+                    v = make_float4(buf_load(wsrc, o, 0), buf_load(wsrc, o + 4u, 0), buf_load(wsrc, o + 8u, 0), buf_load(wsrc, o + 12u, 0));
+                } else if (it < items && row < a.M && k < a.K) {
+                    float e[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int kk = k + t;
-                            float x = 0.0f;
-                            if (kk < a.K) {
-                                if (MODE == MODE_DGRAD) {
-                                    const int c = kk / 9, tap = kk - 9 * c;
-                                    x = a.W[(long long)c * a.Cin * 9 + row * 9 + (8 - tap)];  // W[co=c, ci=row, flipped tap]
-                                } else if (MODE == MODE_FWD_CODES) {
-                                    x = a.q[a.idx[(long long)row * a.K + kk]];
-                                } else {
-                                    x = a.W[(long long)row * a.K + kk];
-                                }
-                            }
-                            e[t] = x;
-                        }
-                        v = make_float4(e[0], e[1], e[2], e[3]);
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = k + t;
+                        float x = 0.0f;
+                        if (kk < a.K) x = (MODE == MODE_FWD_CODES) ? a.q[a.idx[(long long)row * a.K + kk]] : a.W[(long long)row * a.K + kk];
+                        e[t] = x;
                     }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
                 }
                 w[u] = v;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PW; ++u) {
                 const int it = base + u * 256 + tid;
                 if (it < items) {
-                    const int rl = it / k4n, k = (it - rl * k4n) * 4;
-                    *reinterpret_cast<float4 *>(&As[(((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4]) = w[u];
+                    const int rl = (int)__umulhi((unsigned)it, k4n_rcp), k = (it - rl * k4n) * 4;
+                    *reinterpret_cast<float4 *>(&As[as_index(rl, k)]) = w[u];
                 }
             }
         }
@@ -431,9 +494,12 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
     };
 
+    AQ_STAMP(2);
+    int tcount_ = 0;
     for (; tile < ntiles; tile += gridDim.x) {
         commit_tile();
         __syncthreads();  // image (and, the first time, tables and weight panel) visible
+        if (tcount_ == 0) AQ_STAMP(3);
         const int next = tile + gridDim.x;
         if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
 
@@ -481,28 +547,36 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             mfmas(av1, bv1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (tcount_ == 0) AQ_STAMP(4);
         const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
         const int oy0 = ty * a.TH;
+        const int ohw = a.OH * a.OW;
+        const long long img = (long long)n * a.M * ohw;
+        const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + img, (unsigned)(a.M * ohw) * 4u);
+        const __amdgpu_buffer_rsrc_t rsd = make_rsrc(a.res ? a.res + img : a.out + img, (unsigned)(a.M * ohw) * 4u);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
-                if (pyx[nt] < 0 || oy >= a.OH) continue;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+            const bool pok = pyx[nt] >= 0 && oy < a.OH;
 #ifdef AQ_EXPERIMENT
-                if (a.dbg & 4) continue;
+            if (a.dbg & 4) continue;
 #endif
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ch = m0 + 16 * m + 4 * kq + r;
-                    if (ch < a.M) {
-                        const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
-                        a.out[o] = a.res ? acc[m][nt][r] + a.res[o] : acc[m][nt][r];
-                    }
+                    const unsigned o = (pok && ch < a.M) ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB;
+                    float v = acc[m][nt][r];
+                    if (a.res) v += buf_load(rsd, o, 0);
+                    buf_store(v, dst, o, 0);
                 }
-            }
+        }
         __syncthreads();  // every wavefront is done with this tile's LDS image
+        if (tcount_ == 0) AQ_STAMP(5);
+        ++tcount_;
     }
+    AQ_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -536,6 +610,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const bool loader = threadIdx.x >= 256;
     const int jn = lane & 15, kq = lane >> 4;
+    AQ_STAMP(0);
 
     int bx = blockIdx.x;
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
@@ -580,9 +655,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     // loader state (register-staged variant): the tile position is fixed for the workgroup, only the
     // image changes from chunk to chunk, so all offsets are computed once
     constexpr int CH4R = CH4 > 0 ? CH4 : 1, JR = CH4 > 0 ? J : 1;
-    int xoff[JR];
+    unsigned xvo[JR];      // register-staged variant: byte offset inside a channel, or BUF_OOB
+    bool xin[JR];          // element belongs to the plane
+    unsigned dvo[8 * MG];  // byte offset of this thread's dy elements inside an image, or BUF_OOB
     float sv[CH4R][JR], dvr[8 * MG];
     const int pr = tid & (npix - 1), cstep = 256 / npix;
+    const int chs = a.Ho * a.Wo, xchs = a.H * a.Wd;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     int poff = -1;
     if (loader) {
         const int py = pr / a.TW, px = pr - py * a.TW;
@@ -595,26 +674,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
                 const int r = e / a.pitch, cc = e - r * a.pitch;
                 const int gy = r0 + r, gx = c0 + cc;
                 const bool ok = e < a.plane && gy >= 0 && gx >= 0 && gy < a.H && gx < a.Wd;
-                xoff[j] = ok ? gy * a.Wd + gx : (e < a.plane ? -1 : -2);
+                xvo[j] = ok ? (unsigned)(gy * a.Wd + gx) * 4u : BUF_OOB;
+                xin[j] = e < a.plane;
+            }
+#pragma unroll
+            for (int u = 0; u < 8 * MG; ++u) {
+                const int c = tid / npix + cstep * u;
+                const int co = m0 + c;
+                dvo[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? (unsigned)(co * chs + poff) * 4u : BUF_OOB;
             }
         }
     }
     auto fetch_chunk = [&](int im) {
         const int n = ig * a.IPB + im;
-        const float *__restrict__ sdy = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
-        const float *__restrict__ sx = a.x + (long long)n * a.Cin * a.H * a.Wd;
-        const int chs = a.Ho * a.Wo, xchs = a.H * a.Wd;
+        const __amdgpu_buffer_rsrc_t sdy = make_rsrc(a.dy + (long long)n * a.Cout * chs, (unsigned)(a.Cout * chs) * 4u);
+        const __amdgpu_buffer_rsrc_t sx = make_rsrc(a.x + (long long)n * a.Cin * xchs, (unsigned)(a.Cin * xchs) * 4u);
 #pragma unroll
-        for (int u = 0; u < 8 * MG; ++u) {
-            const int c = tid / npix + cstep * u;
-            const int co = m0 + c;
-            dvr[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? sdy[(long long)co * chs + poff] : 0.0f;
-        }
+        for (int u = 0; u < 8 * MG; ++u) dvr[u] = buf_load(sdy, dvo[u], 0);
 #pragma unroll
         for (int u = 0; u < CH4R; ++u) {
-            const int c = wave + 4 * u;
+            const int c = min(wave_s + 4 * u, a.Cin - 1);  // channels beyond Cin are never committed
+            const unsigned soff = (unsigned)(c * xchs) * 4u;
 #pragma unroll
-            for (int j = 0; j < JR; ++j) sv[u][j] = (c < a.Cin && xoff[j] >= 0) ? sx[(long long)c * xchs + xoff[j]] : 0.0f;
+            for (int j = 0; j < JR; ++j) sv[u][j] = buf_load(sx, xvo[j], soff);
         }
     };
     auto commit_chunk = [&](int im) {
@@ -630,10 +712,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             const int c = wave + 4 * u;
 #pragma unroll
             for (int j = 0; j < JR; ++j)
-                if (c < a.Cin && xoff[j] != -2) xs[c * a.plane + lane + 64 * j] = sv[u][j];
+                if (c < a.Cin && xin[j]) xs[c * a.plane + lane + 64 * j] = sv[u][j];
         }
     };
     if (CH4 > 0 && loader && nch > 0) fetch_chunk(0);
+    AQ_STAMP(1);
 
     for (int im = 0; im <= nch; ++im) {
         if (loader) {
@@ -706,8 +789,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
                 }
             }
         }
+        AQ_STAMP(2 + (im < 9 ? im : 9));  // before the barrier: own work of phase im done
         __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
     }
+    AQ_STAMP(12);
 
     // ---- sum the 4 compute wavefronts in LDS (fixed order 0+1+2+3), write the workgroup's slab ------
     float *part = a.part + (long long)blockIdx.x * a.Cout * a.K9;
@@ -747,6 +832,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             }
         }
     }
+    AQ_STAMP(13);
 }
 
 // dW[i] = sum over the workgroup slabs.  A workgroup owns 32 consecutive elements; 8 thread rows
@@ -852,8 +938,11 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
     // persistent kernel: full-width tiles, channels and plane within the register-staging budget
     const int CH4 = (a.KC + 3) / 4, J = (a.plane + 63) / 64;
     const size_t plds = ((size_t)a.Kpad + (size_t)MT * 16 * a.Kpad + (size_t)a.KC * a.plane) * 4;
-    if (a.tiles_x == 1 && CH4 <= 16 && J <= 9 && CH4 * J <= 48 && a.pitch <= 65 && plds <= 160 * 1024) {
+    const bool fits32 = (long long)a.KC * a.IH * a.IW * 4 < (1LL << 31) && (long long)a.M * a.OH * a.OW * 4 < (1LL << 31) &&
+                        (long long)a.Cout * a.Cin * 36 < (1LL << 31);  // buffer offsets
+    if (a.tiles_x == 1 && CH4 <= 16 && J <= 9 && CH4 * J <= 48 && a.pitch <= 65 && plds <= 160 * 1024 && fits32) {
         const int pitch_mul = (65536 + a.pitch - 1) / a.pitch;
+        const unsigned k4n_rcp = (unsigned)(((1ULL << 32) + (a.Kpad >> 2) - 1) / (a.Kpad >> 2));  // it / (Kpad/4) == umulhi(it, rcp) for it < 2^16
         int tw_shift = 0;
         while ((1 << tw_shift) < a.TW) ++tw_shift;
         // workgroups: as many as fit on the chip at once (LDS-limited, at most 2 per CU), each walking
@@ -868,7 +957,7 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
     {                                                                                                                             \
         auto kern = conv_gemm_persist_kernel<MM, NN, CC, JJ, MODE>;                                                               \
         if (plds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
-        hipLaunchKernelGGL(kern, pgrid, dim3(256), plds, st, a, (int)gx, pitch_mul, tw_shift);                                   \
+        hipLaunchKernelGGL(kern, pgrid, dim3(256), plds, st, a, (int)gx, pitch_mul, tw_shift, k4n_rcp);                          \
     }
 #define AQ_PJ(MM, NN, CC)                                 \
         if (jj == 2) AQ_P(MM, NN, CC, 2)                  \
@@ -921,6 +1010,13 @@ static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, c
 } // namespace aq
 
 extern "C" {
+
+#ifdef AQ_EXPERIMENT
+int aq_debug_read_trace(long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(aq::aq_trace), sizeof(long long) * 96);
+}
+#endif
 
 int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
 {
@@ -1078,7 +1174,8 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     // register-staged loader when the tile spans the output width and the image fits the budget
     const int c4 = (a.Cin + 3) / 4, jx = (a.plane + 63) / 64;
     int variant = 0;
-    if (a.tiles_x == 1) {
+    const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
+    if (a.tiles_x == 1 && fits32) {
         if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) variant = 1;
         else if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) variant = 2;
         else if (NG == 18 && c4 <= 8 && jx <= 3) variant = 3;
