@@ -589,6 +589,8 @@ struct WgradArgs {
     int TW, TH, tiles_x, tiles_y;
     int pitch, rows_in, plane;   // LDS image of x
     int cpitch;                  // LDS pitch of a dy channel (TH*TW + 2)
+    int tw_shift, npix_shift;    // TW and TH*TW are powers of two
+    int pitch_mul;               // e / pitch == (e * pitch_mul) >> 16 for e < 1024, pitch <= 65
     int IPB;                     // images per workgroup
     int ngroups_img;             // ceil(N / IPB)
 };
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int pp = 4 * t + kq;
-        const int py = pp / a.TW, px = pp - py * a.TW;
+        const int py = pp >> a.tw_shift, px = pp & (a.TW - 1);
         toff[t] = py * a.stride * a.pitch + px * a.stride;
     }
 
@@ -658,20 +660,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     unsigned xvo[JR];      // register-staged variant: byte offset inside a channel, or BUF_OOB
     bool xin[JR];          // element belongs to the plane
     unsigned dvo[8 * MG];  // byte offset of this thread's dy elements inside an image, or BUF_OOB
-    float sv[CH4R][JR], dvr[8 * MG];
+    constexpr bool DEEP_SETS = CH4 > 0 && MG * NG <= 9 && CH4 * J <= 16;
+    float svA[CH4R][JR], dvA[8 * MG];                                        // staging set A
+    float svB[DEEP_SETS ? CH4R : 1][DEEP_SETS ? JR : 1], dvB[DEEP_SETS ? 8 * MG : 1];  // set B (two chunks in flight)
     const int pr = tid & (npix - 1), cstep = 256 / npix;
     const int chs = a.Ho * a.Wo, xchs = a.H * a.Wd;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     int poff = -1;
     if (loader) {
-        const int py = pr / a.TW, px = pr - py * a.TW;
+        const int py = pr >> a.tw_shift, px = pr & (a.TW - 1);
         const int oy = oy0 + py, ox = ox0 + px;
         poff = (oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
         if (CH4 > 0) {
 #pragma unroll
             for (int j = 0; j < JR; ++j) {
                 const int e = lane + 64 * j;
-                const int r = e / a.pitch, cc = e - r * a.pitch;
+                const int r = (e * a.pitch_mul) >> 16, cc = e - r * a.pitch;
                 const int gy = r0 + r, gx = c0 + cc;
                 const bool ok = e < a.plane && gy >= 0 && gx >= 0 && gy < a.H && gx < a.Wd;
                 xvo[j] = ok ? (unsigned)(gy * a.Wd + gx) * 4u : BUF_OOB;
@@ -679,13 +683,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             }
 #pragma unroll
             for (int u = 0; u < 8 * MG; ++u) {
-                const int c = tid / npix + cstep * u;
+                const int c = (tid >> a.npix_shift) + cstep * u;
                 const int co = m0 + c;
                 dvo[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? (unsigned)(co * chs + poff) * 4u : BUF_OOB;
             }
         }
     }
-    auto fetch_chunk = [&](int im) {
+    auto fetch_chunk = [&](int im, auto &sv, auto &dvr) {
         const int n = ig * a.IPB + im;
         const __amdgpu_buffer_rsrc_t sdy = make_rsrc(a.dy + (long long)n * a.Cout * chs, (unsigned)(a.Cout * chs) * 4u);
         const __amdgpu_buffer_rsrc_t sx = make_rsrc(a.x + (long long)n * a.Cin * xchs, (unsigned)(a.Cin * xchs) * 4u);
@@ -699,12 +703,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             for (int j = 0; j < JR; ++j) sv[u][j] = buf_load(sx, xvo[j], soff);
         }
     };
-    auto commit_chunk = [&](int im) {
+    auto commit_chunk = [&](int im, const auto &sv, const auto &dvr) {
         float *dys = smem + (im & 1) * bufsz;
         float *xs = dys + 16 * MG * a.cpitch;
 #pragma unroll
         for (int u = 0; u < 8 * MG; ++u) {
-            const int c = tid / npix + cstep * u;
+            const int c = (tid >> a.npix_shift) + cstep * u;
             if (c < 16 * MG) dys[c * a.cpitch + pr] = dvr[u];
         }
 #pragma unroll
@@ -715,82 +719,168 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
                 if (c < a.Cin && xin[j]) xs[c * a.plane + lane + 64 * j] = sv[u][j];
         }
     };
-    if (CH4 > 0 && loader && nch > 0) fetch_chunk(0);
-    AQ_STAMP(1);
-
-    for (int im = 0; im <= nch; ++im) {
-        if (loader) {
-            if (CH4 > 0) {
-                if (im < nch) commit_chunk(im);          // loaded during the previous phase
-                if (im + 1 < nch) fetch_chunk(im + 1);   // lands during the next compute phase
-            } else if (im < nch) {
-                const int n = ig * a.IPB + im;
-                float *dys = smem + (im & 1) * bufsz;
-                float *xs = dys + 16 * MG * a.cpitch;
-                // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout; the dy values
-                // wait in registers while the x image loads are issued behind them (one round trip)
-                const float *src = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
-                const int chs = a.Ho * a.Wo;
+    // compute wavefronts: one chunk (TH x TW pixels of one image) from LDS buffer (cidx & 1)
+    auto compute_chunk = [&](int cidx) {
+        const float *dys = smem + (cidx & 1) * bufsz;
+        const float *xs = dys + 16 * MG * a.cpitch;
+        // steps: (pixel block pb = wave, wave+4, ..) x (t = 0..3); two register sets alternate so that
+        // the LDS reads of the next step are in flight during the MFMAs of the current one
+        const int nsteps = ((nblk16 - wave + 3) >> 2) * 4;
+        float av0[MG], av1[MG], bv0[NG], bv1[NG];
+        auto load_step = [&](int sidx, float (&av)[MG], float (&bv)[NG]) {
+            const int s2 = sidx < nsteps ? sidx : nsteps - 1;
+            const int p16 = (wave + 4 * (s2 >> 2)) * 16, t = s2 & 3;
+            const int py = p16 >> a.tw_shift, px = p16 & (a.TW - 1);
+            const int bo = py * a.stride * a.pitch + px * a.stride + toff[t];
 #pragma unroll
-                for (int u = 0; u < 8 * MG; ++u) {
-                    const int c = tid / npix + cstep * u;
-                    const int co = m0 + c;
-                    dvr[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
-                }
-                stage_image(xs, a.x + (long long)n * a.Cin * a.H * a.Wd, a.Cin, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
+            for (int m = 0; m < MG; ++m) av[m] = dys[(16 * m + jn) * a.cpitch + p16 + 4 * t + kq];
 #pragma unroll
-                for (int u = 0; u < 8 * MG; ++u) {
-                    const int c = tid / npix + cstep * u;
-                    if (c < 16 * MG) dys[c * a.cpitch + pr] = dvr[u];
+            for (int g = 0; g < NG; ++g) bv[g] = xs[bo + joff[g]];
+        };
+        auto mfmas = [&](const float (&av)[MG], const float (&bv)[NG]) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[g], acc[m][g], 0, 0, 0);
+        };
+        if (MG * NG <= 9) {
+            if (nsteps > 0) {
+                load_step(0, av0, bv0);
+                for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
+                    load_step(sidx + 1, av1, bv1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(av0, bv0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_step(sidx + 2, av0, bv0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(av1, bv1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        } else if (im >= 1) {
-            const float *dys = smem + ((im - 1) & 1) * bufsz;
-            const float *xs = dys + 16 * MG * a.cpitch;
-            // steps: (pixel block pb = wave, wave+4, ..) x (t = 0..3); two register sets alternate so that
-            // the LDS reads of the next step are in flight during the MFMAs of the current one
-            const int nsteps = ((nblk16 - wave + 3) >> 2) * 4;
-            float av0[MG], av1[MG], bv0[NG], bv1[NG];
-            auto load_step = [&](int sidx, float (&av)[MG], float (&bv)[NG]) {
+        } else if (nsteps > 0) {
+            // large tile groups: one operand set (register budget), pipelined by halves: while the
+            // MFMAs of one half of the n-tiles run, the LDS reads of the other half are in flight
+            constexpr int H1 = NG / 2;
+            auto step_offsets = [&](int sidx, int &ao, int &bo) {
                 const int s2 = sidx < nsteps ? sidx : nsteps - 1;
                 const int p16 = (wave + 4 * (s2 >> 2)) * 16, t = s2 & 3;
-                const int py = p16 / a.TW, px = p16 - py * a.TW;
-                const int bo = py * a.stride * a.pitch + px * a.stride + toff[t];
-#pragma unroll
-                for (int m = 0; m < MG; ++m) av[m] = dys[(16 * m + jn) * a.cpitch + p16 + 4 * t + kq];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) bv[g] = xs[bo + joff[g]];
+                const int py = p16 >> a.tw_shift, px = p16 & (a.TW - 1);
+                bo = py * a.stride * a.pitch + px * a.stride + toff[t];
+                ao = p16 + 4 * t + kq;
             };
-            auto mfmas = [&](const float (&av)[MG], const float (&bv)[NG]) {
+            auto load_av = [&](int sidx, float (&av)[MG]) {
+                int ao, bo;
+                step_offsets(sidx, ao, bo);
+#pragma unroll
+                for (int m = 0; m < MG; ++m) av[m] = dys[(16 * m + jn) * a.cpitch + ao];
+            };
+            auto load_bv = [&](int sidx, int g0, int g1) {
+                int ao, bo;
+                step_offsets(sidx, ao, bo);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    if (g >= g0 && g < g1) bv0[g] = xs[bo + joff[g]];
+            };
+            auto mfma_part = [&](const float (&av)[MG], int g0, int g1) {
 #pragma unroll
                 for (int m = 0; m < MG; ++m)
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[g], acc[m][g], 0, 0, 0);
+                        if (g >= g0 && g < g1) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv0[g], acc[m][g], 0, 0, 0);
             };
-            if (MG * NG <= 9) {
-                if (nsteps > 0) {
-                    load_step(0, av0, bv0);
-                    for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
-                        load_step(sidx + 1, av1, bv1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mfmas(av0, bv0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_step(sidx + 2, av0, bv0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mfmas(av1, bv1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else {  // large tile groups: one operand set (register budget), 18 MFMAs cover the reads
-                for (int sidx = 0; sidx < nsteps; ++sidx) {
-                    load_step(sidx, av0, bv0);
-                    mfmas(av0, bv0);
-                }
+            load_av(0, av0);
+            load_bv(0, 0, H1);
+            for (int sidx = 0; sidx < nsteps; sidx += 2) {  // nsteps is a multiple of 4
+                load_bv(sidx, H1, NG);
+                load_av(sidx + 1, av1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_part(av0, 0, H1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bv(sidx + 1, 0, H1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_part(av0, H1, NG);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bv(sidx + 1, H1, NG);
+                load_av(sidx + 2, av0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_part(av1, 0, H1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bv(sidx + 2, 0, H1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_part(av1, H1, NG);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        AQ_STAMP(2 + (im < 9 ? im : 9));  // before the barrier: own work of phase im done
-        __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
+    };
+    // loader wavefronts, generic variant: chunk im straight into LDS buffer (im & 1)
+    auto load_generic = [&](int im) {
+        const int n = ig * a.IPB + im;
+        float *dys = smem + (im & 1) * bufsz;
+        float *xs = dys + 16 * MG * a.cpitch;
+        // dy tile: [16*MG channels][npix], zero outside the output / beyond Cout; the dy values
+        // wait in registers while the x image loads are issued behind them (one round trip)
+        const float *src = a.dy + (long long)n * a.Cout * a.Ho * a.Wo;
+        const int chs = a.Ho * a.Wo;
+#pragma unroll
+        for (int u = 0; u < 8 * MG; ++u) {
+            const int c = (tid >> a.npix_shift) + cstep * u;
+            const int co = m0 + c;
+            dvA[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
+        }
+        stage_image(xs, a.x + (long long)n * a.Cin * a.H * a.Wd, a.Cin, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
+#pragma unroll
+        for (int u = 0; u < 8 * MG; ++u) {
+            const int c = (tid >> a.npix_shift) + cstep * u;
+            if (c < 16 * MG) dys[c * a.cpitch + pr] = dvA[u];
+        }
+    };
+    // Pipeline (register-staged variant).  DEEP (small tile groups, where registers allow a second staging
+    // set): chunk p is fetched into registers during phase p-2, written to LDS buffer (p & 1) in phase p
+    // and consumed in phase p+1, so a load has two phases to land (one phase is shorter than the memory
+    // latency); phases come in pairs so that the register set of a chunk (A: even, B: odd) is a
+    // compile-time choice.  Otherwise chunk p is fetched during phase p-1.
+    constexpr bool DEEP = CH4 > 0 && MG * NG <= 9 && CH4 * J <= 16;
+    if (CH4 > 0 && loader) {
+        if (nch > 0) fetch_chunk(0, svA, dvA);
+        if (DEEP && nch > 1) fetch_chunk(1, svB, dvB);
+    }
+    AQ_STAMP(1);
+    if constexpr (DEEP) {
+        for (int im = 0; im <= nch; im += 2) {
+            if (loader) {
+                if (im < nch) commit_chunk(im, svA, dvA);
+                if (im + 2 < nch) fetch_chunk(im + 2, svA, dvA);
+            } else if (im >= 1) {
+                compute_chunk(im - 1);
+            }
+            AQ_STAMP(2 + (im < 9 ? im : 9));  // before the barrier: own work of phase im done
+            __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
+            if (im + 1 > nch) break;
+            if (loader) {
+                if (im + 1 < nch) commit_chunk(im + 1, svB, dvB);
+                if (im + 3 < nch) fetch_chunk(im + 3, svB, dvB);
+            } else {
+                compute_chunk(im);
+            }
+            AQ_STAMP(2 + (im + 1 < 9 ? im + 1 : 9));
+            __syncthreads();
+        }
+    } else {
+        for (int im = 0; im <= nch; ++im) {
+            if (loader) {
+                if (CH4 > 0) {
+                    if (im < nch) commit_chunk(im, svA, dvA);          // loaded during the previous phase
+                    if (im + 1 < nch) fetch_chunk(im + 1, svA, dvA);   // lands during the next compute phase
+                } else if (im < nch) {
+                    load_generic(im);
+                }
+            } else if (im >= 1) {
+                compute_chunk(im - 1);
+            }
+            AQ_STAMP(2 + (im < 9 ? im : 9));
+            __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
+        }
     }
     AQ_STAMP(12);
 
@@ -1055,6 +1145,49 @@ int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, in
     return launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), "aq_conv_dgrad");
 }
 
+// LDS bank conflicts of the wgrad operand reads: the 16 lanes jn of a wavefront read 16 consecutive
+// (ci, tap) columns of the x image and the lane groups kq read neighbouring pixels, 32 lanes (kq pair)
+// per LDS cycle over 32 banks.  Returns the number of extra LDS cycles summed over the column phases.
+static int wgrad_bank_cost(int pitch, int plane, int stride, int K9)
+{
+    int cost = 0;
+    for (int j0 = 0; j0 < K9 && j0 < 18 * 16; j0 += 16)
+        for (int half = 0; half < 2; ++half) {
+            int addr[32][32], n[32] = {0};
+            for (int jn = 0; jn < 16; ++jn) {
+                const int jcol = j0 + jn;
+                if (jcol >= K9) continue;
+                const int ci = jcol / 9, tap = jcol % 9;
+                for (int kq = 2 * half; kq < 2 * half + 2; ++kq) {
+                    const int ad = ci * plane + (tap / 3) * pitch + tap % 3 + kq * stride, b = ad & 31;
+                    bool seen = false;
+                    for (int i = 0; i < n[b]; ++i) seen = seen || addr[b][i] == ad;
+                    if (!seen) addr[b][n[b]++] = ad;
+                }
+            }
+            int worst = 1;
+            for (int b = 0; b < 32; ++b) worst = n[b] > worst ? n[b] : worst;
+            cost += worst - 1;
+        }
+    return cost;
+}
+
+// pitch (<= 65) and plane of the LDS x image, padded so that the operand reads spread over the banks
+static void wgrad_pad(int stride, int K9, int rows_in, int &pitch, int &plane)
+{
+    int best = 1 << 30, bp = pitch, bpl = rows_in * pitch;
+    const int limit = ((rows_in * pitch + 63) / 64) * 64;  // same number of 64-element slices as unpadded
+    for (int p = pitch; p <= pitch + 8 && p <= 65; ++p)
+        for (int extra = 0; extra < 32; ++extra) {
+            const int pl = rows_in * p + extra;
+            if (pl > limit) continue;
+            const int score = wgrad_bank_cost(p, pl, stride, K9) * 4096 + pl;  // conflicts first, then size
+            if (score < best) { best = score; bp = p; bpl = pl; }
+        }
+    pitch = bp;
+    plane = bpl;
+}
+
 static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &lds, size_t &ws_bytes)
 {
     using namespace aq;
@@ -1075,7 +1208,18 @@ static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &ld
     a.pitch = (a.TW - 1) * a.stride + 3;
     a.rows_in = (a.TH - 1) * a.stride + 3;
     a.plane = a.rows_in * a.pitch;
+    {   // pad the LDS image against bank conflicts when that keeps the per-lane element count (the kernel
+        // variants are instantiated per count) and the LDS budget
+        int pp = a.pitch, pl = a.plane;
+        wgrad_pad(a.stride, a.K9, a.rows_in, pp, pl);
+        const size_t need = 2 * ((size_t)16 * MG * (a.TH * a.TW + 2) + (size_t)a.Cin * pl) * 4;
+        if ((pl + 63) / 64 == (a.plane + 63) / 64 && need <= 160 * 1024) { a.pitch = pp; a.plane = pl; }
+    }
     a.cpitch = a.TH * a.TW + 2;
+    a.tw_shift = a.npix_shift = 0;
+    while ((1 << a.tw_shift) < a.TW) ++a.tw_shift;
+    while ((1 << a.npix_shift) < a.TH * a.TW) ++a.npix_shift;
+    a.pitch_mul = (65536 + a.pitch - 1) / a.pitch;
     const int gy = (mtiles + MG - 1) / MG, gz = (ntiles + NG - 1) / NG;
     // images per workgroup: keep >= ~256 workgroups in flight, at most 8 images each
     long long chunks = (long long)a.N * a.tiles_x * a.tiles_y;
