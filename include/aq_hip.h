@@ -166,6 +166,25 @@ int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma
                         void *stream);
 size_t aq_bn_workspace_bytes(int N, int C, int HW);
 
+/* `self.convK(F.relu(self.bnK(x)))` of a block (adp_qtz_fan.py:674-676, 690-691) without writing the
+ * activated tensor: aq_bnconv_fwd computes the batch statistics of the raw x (one small launch), then the
+ * convolution normalises + rectifies its input while staging it into LDS and adds res (may be NULL) in its
+ * epilogue; save_mean / save_rstd / running statistics as aq_bn_relu_fwd.  aq_bnconv_wgrad_partial is
+ * aq_conv_wgrad_partial with the same transformation of x (recomputed from the saved statistics).  The
+ * input gradient is aq_conv_dgrad followed by aq_bn_relu_bwd on the raw x.  Only for shapes where
+ * aq_bnconv_supported returns 1 (others: -ENOTSUP; use the separate entry points).
+ * workspace of aq_bnconv_fwd: aq_bn_workspace_bytes(N, Cin, H*Wd). */
+int aq_bnconv_supported(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad);
+int aq_bnconv_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                  float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                  const float *W, const float *res, float *y, float *save_mean, float *save_rstd, int N,
+                  int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *workspace,
+                  size_t workspace_bytes, void *stream);
+int aq_bnconv_wgrad_partial(const float *x, const float *gamma, const float *beta, const float *save_mean,
+                            const float *save_rstd, const float *dy, int N, int Cin, int H, int Wd,
+                            int Cout, int ksize, int stride, int pad, void *workspace,
+                            size_t workspace_bytes, int *nslab, void *stream);
+
 /* Shortcut of the dimension-increasing blocks, nn.Sequential(nn.AvgPool2d(2), nn.ZeroPad2d((0, 0, 0, 0,
  * C/2, C/2))) (adp_qtz_fan.py:669-671): y[N, pad_front+C+pad_back, H/2, W/2] = 2x2 average of x[N, C, H, W]
  * in channels [pad_front, pad_front+C), zero elsewhere; and its gradient dx[N, C, H, W]. */

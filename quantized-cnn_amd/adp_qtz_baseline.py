@@ -10,14 +10,25 @@ import torch.nn as nn
 from . import layers
 
 
-def _conv(conv, x, res=None):
+def _ours(conv, x):
+    return (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.bias is None
+            and conv.groups == 1 and conv.dilation == (1, 1) and x.is_cuda)
+
+
+def _conv(conv, x, res=None, bn=None, split=False):
     """nn.Conv2d module applied through the MFMA kernels when it is a 3x3 / pad 1 / stride 1|2 / no-bias
-    convolution on the HIP device (all convolutions of this model are)."""
-    if (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.bias is None
-            and conv.groups == 1 and conv.dilation == (1, 1) and x.is_cuda):
+    convolution on the HIP device (all convolutions of this model are); bn: BatchNorm2d whose relu(bn(x))
+    is the input; split: also return x for the caller's shortcut."""
+    if _ours(conv, x):
+        if bn is not None:
+            return layers.bn_relu_conv(bn, x, conv.weight, conv.stride[0], None, res, split)
         return layers._Conv3x3.apply(x, conv.weight, conv.stride[0], None, res)
+    xs = x
+    if bn is not None:
+        x = layers.bn_relu(bn, x)
     y = conv(x)
-    return y if res is None else y + res
+    y = y if res is None else y + res
+    return (y, xs) if split else y
 
 
 class Residual(layers._Block):
@@ -33,9 +44,8 @@ class Residual(layers._Block):
         self.shortcut = self._shortcut(in_channel, increase_dim)
 
     def forward(self, x):
-        out, xs = layers.bn_relu(self.bn1, x, split=True)
-        out = layers.bn_relu(self.bn2, _conv(self.conv1, out))
-        return _conv(self.conv2, out, res=self._apply_shortcut(xs))
+        out, xs = _conv(self.conv1, x, bn=self.bn1, split=True)
+        return _conv(self.conv2, out, res=self._apply_shortcut(xs), bn=self.bn2)
 
 
 class PreResidual(layers._Block):
@@ -48,8 +58,7 @@ class PreResidual(layers._Block):
         self.conv2 = nn.Conv2d(in_channel, in_channel, kernel_size=3, stride=1, padding=1, bias=False)
 
     def forward(self, x):
-        out = layers.bn_relu(self.bn2, _conv(self.conv1, x))
-        return _conv(self.conv2, out, res=x)
+        return _conv(self.conv2, _conv(self.conv1, x), res=x, bn=self.bn2)
 
 
 class ResNet(nn.Module):

@@ -16,30 +16,10 @@
 // (<= 8.4 MB) stay in L2 / Infinity Cache between the two launches; the kernels are bandwidth- and
 // launch-bound.
 #include "aq_common.h"
+#include "aq_bn_shared.h"
 #include "../../include/aq_hip.h"
 
 namespace aq {
-
-constexpr int BN_T = 256;
-constexpr int BN_MAX_PARTS = 64;  // partial blocks per channel (merged by one wavefront)
-
-struct BnGeom {
-    int N, C, HW;
-    int S, npb;    // reduction launches: S blocks per channel, npb images per block
-    int S2, npb2;  // streaming launches
-};
-
-static BnGeom bn_geom(int N, int C, int HW)
-{
-    BnGeom g{N, C, HW, 1, 1, 1, 1};
-    int npb = HW >= 2048 ? 1 : 2048 / HW;
-    g.npb2 = npb;
-    g.S2 = (N + npb - 1) / npb;
-    const int cap = (N + BN_MAX_PARTS - 1) / BN_MAX_PARTS;
-    g.npb = npb > cap ? npb : cap;
-    g.S = (N + g.npb - 1) / g.npb;
-    return g;
-}
 
 typedef float vec4 __attribute__((ext_vector_type(4)));
 
@@ -57,13 +37,6 @@ template <> struct Vec<1> {
     __device__ float &operator[](int) { return v; }
 };
 
-__device__ inline float wave_sum(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 // sum over the 256 threads of a block, result in every thread; sh holds 4 floats
 __device__ inline float block_sum(float v, float *sh)
 {
@@ -72,12 +45,6 @@ __device__ inline float block_sum(float v, float *sh)
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-__device__ inline void scale_shift(float gamma, float beta, float mean, float rstd, float &scale, float &shift)
-{
-    scale = gamma * rstd;
-    shift = __builtin_fmaf(-mean, scale, beta);
 }
 
 // iterate over the vectors of channel c in images [n0, n1): f(offset into the tensor)
@@ -122,12 +89,7 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict_
 struct BnApplyArgs {
     const float *x;
     float *y;
-    const float2 *part;
-    const float *gamma, *beta;
-    float *running_mean, *running_var;
-    long long *num_batches_tracked;
-    float *save_mean, *save_rstd;
-    float eps, momentum;
+    BnStatsIn st;
     int eval;
 };
 
@@ -138,32 +100,12 @@ __device__ inline void bn_finalize(const BnApplyArgs &a, const BnGeom &g, int c,
     if (threadIdx.x < 64) {
         float mean, rstd;
         if (a.eval) {
-            mean = a.running_mean[c];
-            rstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+            mean = a.st.running_mean[c];
+            rstd = 1.0f / sqrtf(a.st.running_var[c] + a.st.eps);
         } else {
-            // merge the S partials: mean = sum n_s mean_s / n, M2 = sum M2_s + sum n_s (mean_s - mean)^2
-            const int s = threadIdx.x;
-            const bool on = s < g.S;
-            const float2 p = on ? a.part[c * g.S + s] : make_float2(0.0f, 0.0f);
-            const float ns = on ? (float)(min(g.N, (s + 1) * g.npb) - s * g.npb) * (float)g.HW : 0.0f;
-            const float cnt = (float)g.N * (float)g.HW;
-            mean = wave_sum(ns * p.x) / cnt;
-            const float d = p.x - mean;
-            const float M2 = wave_sum(p.y + ns * d * d);
-            const float var = M2 / cnt;
-            rstd = 1.0f / sqrtf(var + a.eps);
-            if (threadIdx.x == 0 && blockIdx.x == 0) {
-                a.save_mean[c] = mean;
-                a.save_rstd[c] = rstd;
-                if (a.running_mean) {
-                    const float unbiased = M2 / fmaxf(cnt - 1.0f, 1.0f);
-                    a.running_mean[c] = __builtin_fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
-                    a.running_var[c] = __builtin_fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
-                }
-                if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-            }
+            bn_channel_stats(a.st, g, c, threadIdx.x, blockIdx.x == 0, mean, rstd);
         }
-        if (threadIdx.x == 0) scale_shift(a.gamma[c], a.beta[c], mean, rstd, sc[0], sc[1]);
+        if (threadIdx.x == 0) scale_shift(a.st.gamma[c], a.st.beta[c], mean, rstd, sc[0], sc[1]);
     }
     __syncthreads();
 }
@@ -305,6 +247,13 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int launch_bn_stats(const float *x, float2 *part, const BnGeom &g, hipStream_t st)
+{
+    if (g.HW % 4 == 0 && aligned16(x)) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(g.S, g.C), dim3(BN_T), 0, st, x, part, g);
+    else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.S, g.C), dim3(BN_T), 0, st, x, part, g);
+    return check_launch("bn statistics");
+}
+
 static int check_dims(const char *fn, int N, int C, int HW, bool batch_stats)
 {
     AQ_REQUIRE(N >= 1 && C >= 1 && HW >= 1, -EINVAL, "%s: bad sizes N=%d C=%d HW=%d", fn, N, C, HW);
@@ -345,11 +294,10 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
         AQ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), -EINVAL, "aq_bn_relu_fwd: running_mean and running_var go together");
         AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_fwd: workspace of %zu bytes needed, %zu given",
                    (size_t)C * g.S * sizeof(float2), workspace_bytes);
-        if (vec) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(g.S, C), dim3(BN_T), 0, st, x, static_cast<float2 *>(workspace), g);
-        else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.S, C), dim3(BN_T), 0, st, x, static_cast<float2 *>(workspace), g);
+        launch_bn_stats(x, static_cast<float2 *>(workspace), g, st);
     }
-    BnApplyArgs a{x, y, static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
-                  save_mean, save_rstd, eps, momentum, eval ? 1 : 0};
+    BnApplyArgs a{x, y, BnStatsIn{static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
+                                  save_mean, save_rstd, eps, momentum}, eval ? 1 : 0};
     const dim3 grid(g.S2, C);
     if (pool) {
         const dim3 pgrid((N + 3) / 4, C);

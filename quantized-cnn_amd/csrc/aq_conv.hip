@@ -21,6 +21,7 @@
 // summed through LDS in a fixed order and the workgroup writes one partial slab; a second kernel
 // adds the slabs of all workgroups in ascending order.  No atomics anywhere: bit-reproducible.
 #include "aq_common.h"
+#include "aq_bn_shared.h"
 #include "../../include/aq_hip.h"
 
 #include <algorithm>
@@ -82,6 +83,11 @@ struct ConvArgs {
     int pitch, rows_in, plane;
     int Kpad;
     int vecA;            // rows of A are 16-byte aligned and K % 4 == 0
+    // forward only: the input is a raw tensor whose batch normalisation + ReLU is applied while it is staged
+    // (relu(bn(x)) is never written to memory); statistics come as per-slice partials
+    int bn_on;
+    BnStatsIn bn;
+    BnGeom bng;
     int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
 };
 
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // wavefront index as a scalar
 
     float sv[CH4][J];
+    unsigned inmask = 0;  // bit j: element j of the tile being fetched lies inside the tensor
     auto fetch_tile = [&](int tile) {
         const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
         const int r0 = ty * a.TH * a.rs - 1;
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             }
             ok = ok && gy < a.IH;
             off[j] = ok ? (unsigned)(gy * a.IW + gxj[j]) * 4u : BUF_OOB;
+            inmask = j == 0 ? (unsigned)ok : (inmask | ((unsigned)ok << j));
         }
 #ifdef AQ_EXPERIMENT
         if (a.dbg & 2) return;
@@ -385,13 +393,17 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             for (int j = 0; j < J; ++j) sv[u][j] = buf_load(src, off[j], soff);
         }
     };
+    float bsc[CH4], bsh[CH4];  // scale / shift of this wavefront's input channels (uniform)
     auto commit_tile = [&]() {
 #pragma unroll
         for (int u = 0; u < CH4; ++u) {
             const int c = wave + 4 * u;
 #pragma unroll
-            for (int j = 0; j < J; ++j)
-                if (c < a.KC && rj[j] >= 0) xs[c * a.plane + lane + 64 * j] = sv[u][j];
+            for (int j = 0; j < J; ++j) {
+                float v = sv[u][j];
+                if (MODE == MODE_FWD && a.bn_on) v = ((inmask >> j) & 1u) ? fmaxf(__builtin_fmaf(v, bsc[u], bsh[u]), 0.0f) : 0.0f;  // padding stays 0
+                if (c < a.KC && rj[j] >= 0) xs[c * a.plane + lane + 64 * j] = v;
+            }
         }
     };
 
@@ -474,6 +486,31 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             }
         }
     }
+
+    // batch-norm input: every wavefront merges the statistics of the channels it stages (same operation
+    // sequence as the stand-alone kernel); the first workgroup also records them
+    if (MODE == MODE_FWD && a.bn_on) {
+        int cs[CH4];
+        float mean[CH4], rstd[CH4];
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) cs[u] = wave_s + 4 * u < a.KC ? wave_s + 4 * u : -1;
+        float gam[CH4], bet[CH4];  // all loads first: one memory round trip, not one per channel
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) {
+            gam[u] = a.bn.gamma[cs[u] >= 0 ? cs[u] : 0];
+            bet[u] = a.bn.beta[cs[u] >= 0 ? cs[u] : 0];
+        }
+        bn_channel_stats_multi<CH4>(a.bn, a.bng, cs, lane, blockIdx.x == 0 && blockIdx.y == 0, mean, rstd);
+        float sc[CH4], sh[CH4];
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) scale_shift(gam[u], bet[u], mean[u], rstd[u], sc[u], sh[u]);
+#pragma unroll
+        for (int u = 0; u < CH4; ++u) {
+            bsc[u] = sc[u];
+            bsh[u] = sh[u];
+        }
+    }
+    AQ_STAMP(7);
 
     const int nkb = a.Kpad >> 4;
     auto load_a = [&](int kb, float (&av)[MT][4]) {
@@ -584,6 +621,8 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
 struct WgradArgs {
     const float *x, *dy;
     float *part;  // [chunks_groups][Cout*Cin*9]
+    // when bn_mean is set, x is a raw tensor and the operand is relu(batch_norm(x)) with these statistics
+    const float *bn_gamma, *bn_beta, *bn_mean, *bn_rstd;
     int N, Cin, H, Wd, Cout, stride, Ho, Wo;
     int K9;                      // Cin*9
     int TW, TH, tiles_x, tiles_y;
@@ -703,6 +742,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             for (int j = 0; j < JR; ++j) sv[u][j] = buf_load(sx, xvo[j], soff);
         }
     };
+    float wsc[CH4R], wsh[CH4R];
+    if (CH4 > 0 && loader && a.bn_mean) {
+#pragma unroll
+        for (int u = 0; u < CH4R; ++u) {
+            const int c = min(wave_s + 4 * u, a.Cin - 1);
+            scale_shift(a.bn_gamma[c], a.bn_beta[c], a.bn_mean[c], a.bn_rstd[c], wsc[u], wsh[u]);
+        }
+    }
     auto commit_chunk = [&](int im, const auto &sv, const auto &dvr) {
         float *dys = smem + (im & 1) * bufsz;
         float *xs = dys + 16 * MG * a.cpitch;
@@ -715,8 +762,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
         for (int u = 0; u < CH4R; ++u) {
             const int c = wave + 4 * u;
 #pragma unroll
-            for (int j = 0; j < JR; ++j)
-                if (c < a.Cin && xin[j]) xs[c * a.plane + lane + 64 * j] = sv[u][j];
+            for (int j = 0; j < JR; ++j) {
+                float v = sv[u][j];
+                if (a.bn_mean) v = xvo[j] != BUF_OOB ? fmaxf(__builtin_fmaf(v, wsc[u], wsh[u]), 0.0f) : 0.0f;  // padding stays 0
+                if (c < a.Cin && xin[j]) xs[c * a.plane + lane + 64 * j] = v;
+            }
         }
     };
     // compute wavefronts: one chunk (TH x TW pixels of one image) from LDS buffer (cidx & 1)
@@ -992,8 +1042,9 @@ static void pick_tile(int OW, int npix, int &TW, int &TH)
     TH = npix / TW;
 }
 
+// dry: no launch; returns 1 when the persistent kernel (the one that can normalise its input) would run
 template <int MODE>
-static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
+static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false)
 {
     // tile choice: NT = 2 (128 pixels) and MT up to 4, shrunk until the grid fills the chip
     const int mtiles = (a.M + 15) / 16;
@@ -1043,6 +1094,7 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
         const int c4 = CH4 <= 4 ? 4 : (CH4 <= 8 ? 8 : 16);
         const int jj = J <= 2 ? 2 : (J <= 3 ? 3 : (J <= 5 ? 5 : 9));
         bool done = true;
+        if (dry) return ((jj == 5 && c4 > 8) || (jj == 9 && c4 > 4)) ? 0 : 1;
 #define AQ_P(MM, NN, CC, JJ)                                                                                                      \
     {                                                                                                                             \
         auto kern = conv_gemm_persist_kernel<MM, NN, CC, JJ, MODE>;                                                               \
@@ -1070,6 +1122,8 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who)
 #undef AQ_P
         if (done) return check_launch(who);
     }
+    if (dry) return 0;
+    AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
     dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
     if (MT == 4 && NT == 2) AQ_GEMM(4, 2);
@@ -1249,9 +1303,28 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
     return ws;
 }
 
+// register-staged loader variant (0: generic) for a planned launch: the tile must span the output width
+// and the image must fit the staging budget
+static int wgrad_variant(const aq::WgradArgs &a, int MG, int NG)
+{
+    const int c4 = (a.Cin + 3) / 4, jx = (a.plane + 63) / 64;
+    const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
+    if (a.tiles_x != 1 || !fits32) return 0;
+    if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) return 1;
+    if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) return 2;
+    if (NG == 18 && c4 <= 8 && jx <= 3) return 3;
+    if (NG == 18 && c4 <= 8 && jx <= 5) return 4;
+    if (NG == 18 && c4 <= 16 && jx <= 2) return 5;
+    return 0;
+}
+
+struct BnOperand {  // statistics of the batch normalisation applied to x while it is staged (all NULL: none)
+    const float *gamma, *beta, *mean, *rstd;
+};
+
 // slab kernel of aq_conv_wgrad; *nslab_out = number of slabs written to workspace ([nslab][Cout*Cin*9])
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out);
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn = nullptr);
 
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
                   void *workspace, size_t workspace_bytes, void *stream)
@@ -1302,30 +1375,85 @@ int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
     return 0;
 }
 
+int aq_bnconv_supported(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
+{
+    using namespace aq;
+    if (check_conv("aq_bnconv_supported", N, Cin, H, Wd, Cout, ksize, stride, pad) || N < 1) return 0;
+    ConvArgs a = {};
+    a.N = N; a.Cin = Cin; a.Cout = Cout;
+    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
+    if (launch_gemm<MODE_FWD>(a, N, nullptr, "aq_bnconv_supported", true) != 1) return 0;
+    WgradArgs w = {};
+    w.N = N; w.Cin = Cin; w.H = H; w.Wd = Wd; w.Cout = Cout; w.stride = stride;
+    int MG, NG;
+    dim3 grid;
+    size_t lds, ws;
+    if (wgrad_plan(w, MG, NG, grid, lds, ws)) return 0;
+    return wgrad_variant(w, MG, NG) != 0 && (long long)N * H * Wd >= 2;
+}
+
+int aq_bnconv_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                  long long *num_batches_tracked, float eps, float momentum, const float *W, const float *res, float *y, float *save_mean,
+                  float *save_rstd, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *workspace,
+                  size_t workspace_bytes, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_conv("aq_bnconv_fwd", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(N >= 1 && (long long)N * H * Wd >= 2, -EINVAL, "aq_bnconv_fwd: batch statistics need more than one value per channel");
+    AQ_REQUIRE(x && gamma && beta && W && y && save_mean && save_rstd, -EFAULT, "aq_bnconv_fwd: NULL pointer");
+    AQ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), -EINVAL, "aq_bnconv_fwd: running_mean and running_var go together");
+    AQ_REQUIRE(eps >= 0.0f, -EINVAL, "aq_bnconv_fwd: negative eps");
+    const BnGeom g = bn_geom(N, Cin, H * Wd);
+    const size_t need = (size_t)Cin * g.S * sizeof(float2);
+    AQ_REQUIRE(workspace && workspace_bytes >= need, -ENOSPC, "aq_bnconv_fwd: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    AQ_REQUIRE(aq_bnconv_supported(N, Cin, H, Wd, Cout, ksize, stride, pad), -ENOTSUP,
+               "aq_bnconv_fwd: no kernel with fused input normalisation for this shape (see aq_bnconv_supported)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_bn_stats(x, static_cast<float2 *>(workspace), g, st)) return rc;
+    ConvArgs a = {};
+    a.in = x; a.W = W; a.out = y; a.res = res;
+    a.N = N; a.Cin = Cin; a.Cout = Cout;
+    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
+    a.bn_on = 1;
+    a.bn = BnStatsIn{static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd,
+                     eps, momentum};
+    a.bng = g;
+    return launch_gemm<MODE_FWD>(a, N, st, "aq_bnconv_fwd");
+}
+
+int aq_bnconv_wgrad_partial(const float *x, const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
+                            const float *dy, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *workspace,
+                            size_t workspace_bytes, int *nslab, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_conv("aq_bnconv_wgrad_partial", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(nslab && gamma && beta && save_mean && save_rstd, -EFAULT, "aq_bnconv_wgrad_partial: NULL pointer");
+    *nslab = 0;
+    if (N == 0) return 0;
+    const BnOperand bn{gamma, beta, save_mean, save_rstd};
+    return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab, &bn);
+}
+
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out)
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn)
 {
     using namespace aq;
     AQ_REQUIRE(x && dy, -EFAULT, "aq_conv_wgrad: NULL pointer");
     WgradArgs a = {};
     a.x = x; a.dy = dy; a.part = static_cast<float *>(workspace);
+    if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride;
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
     if (int rc = wgrad_plan(a, MG, NG, grid, lds, ws)) return rc;
     AQ_REQUIRE(workspace && workspace_bytes >= ws, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", ws, workspace_bytes);
-    // register-staged loader when the tile spans the output width and the image fits the budget
-    const int c4 = (a.Cin + 3) / 4, jx = (a.plane + 63) / 64;
-    int variant = 0;
-    const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
-    if (a.tiles_x == 1 && fits32) {
-        if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) variant = 1;
-        else if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) variant = 2;
-        else if (NG == 18 && c4 <= 8 && jx <= 3) variant = 3;
-        else if (NG == 18 && c4 <= 8 && jx <= 5) variant = 4;
-        else if (NG == 18 && c4 <= 16 && jx <= 2) variant = 5;
-    }
+    const int variant = wgrad_variant(a, MG, NG);
+    AQ_REQUIRE(variant != 0 || !a.bn_mean, -ENOTSUP, "aq_conv_wgrad: no kernel with fused input normalisation for this shape");
 #define AQ_WGV(MM, NN, CC, JJ)                                                                                                 \
     {                                                                                                                          \
         auto kern = conv_wgrad_kernel<MM, NN, CC, JJ>;                                                                         \

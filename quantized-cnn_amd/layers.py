@@ -185,6 +185,60 @@ def bn_relu_pool(bn, pool, x):
     return pool(bn_relu(bn, x))
 
 
+class _BnReluConv(torch.autograd.Function):
+    """y = conv3x3(relu(batch_norm(x)), W) [+ res] in batch-statistics mode, the activated tensor never
+    written: the convolution normalises its input while staging it, the weight gradient recomputes it
+    from the saved statistics, the input gradient is dgrad followed by the BatchNorm+ReLU backward
+    kernels on the raw x.  split=True also hands x through (second output) so that a shortcut's
+    gradient is added inside the BatchNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, W, stride, dW_slot, res, split):
+        x = x.contiguous()
+        y, mean, rstd = ops.bnconv_forward(x, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
+                                           W, stride, res.contiguous() if res is not None else None)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, W)
+        ctx.stride, ctx.dW_slot = stride, dW_slot
+        return (y, x.view_as(x)) if split else y
+
+    @staticmethod
+    def backward(ctx, dy, dalias=None):
+        x, gamma, beta, mean, rstd, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW = None
+        if ctx.needs_input_grad[4]:
+            if _wgrad_deferred is not None and ctx.dW_slot is not None:
+                ws, nslab = ops.bnconv_wgrad_partial(x, gamma, beta, mean, rstd, dy, ctx.stride)
+                _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
+            else:
+                ws, nslab = ops.bnconv_wgrad_partial(x, gamma, beta, mean, rstd, dy, ctx.stride)
+                dW = ctx.dW_slot if ctx.dW_slot is not None else torch.empty_like(W)
+                ops.conv_wgrad_reduce([(ws, dW, nslab)])
+        dz = ops.conv_dgrad(dy, W, x.shape, ctx.stride)
+        dx, dg, db = ops.bn_relu_backward(dz, x, gamma, beta, mean, rstd, res=dalias.contiguous() if dalias is not None else None)
+        return dx, dg, db, None, dW, None, None, (dy if ctx.needs_input_grad[7] else None), None
+
+
+# The convolution can normalise its input while staging it (no activated tensor in memory).  Measured on
+# MI355X at batch 128 this only breaks even: every wavefront of the convolution has to merge the channel
+# statistics it needs (17.0 against 15.8 + 4.9 us at 16 channels, 22.1 against 14.0 + 4.9 us at 64), so the
+# separate BatchNorm+ReLU kernel stays the default.
+FUSE_BN_INTO_CONV = False
+
+
+def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False):
+    """conv(relu(bn(x)), W) [+ res] -> y or (y, x') with split; with FUSE_BN_INTO_CONV the fused kernel is
+    used when the module is in its usual training configuration and one exists for the shape."""
+    fused = (FUSE_BN_INTO_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
+             and (bn.training or bn.running_mean is None) and ops.bnconv_supported(x.shape, W.shape[0], stride))
+    if fused:
+        return _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split)
+    if split:
+        z, xs = bn_relu(bn, x, split=True)
+        return _Conv3x3.apply(z, W, stride, dW_slot, res), xs
+    return _Conv3x3.apply(bn_relu(bn, x), W, stride, dW_slot, res)
+
+
 class _Shortcut(torch.autograd.Function):
     """AvgPool2d(2) + ZeroPad2d over channels (adp_qtz_fan.py:669-671) as one kernel each way."""
 
@@ -324,17 +378,25 @@ class QConv2d(_QuantBase):
         self.ksize, self.stride, self.padding = ksize, stride, padding
         self._init_levels(config, config.num_level_conv, in_channel * ksize * ksize, s)
 
-    def forward(self, x, res=None):
-        """res: optional tensor added to the output inside the convolution kernel (the shortcut)."""
+    def forward(self, x, res=None, bn=None, split=False):
+        """res: optional tensor added to the output inside the convolution kernel (the shortcut).
+        bn: optional nn.BatchNorm2d whose relu(bn(x)) is the convolution's input (fused where possible);
+        with split=True returns (y, x') where x' is x for the caller's shortcut path."""
         assert len(x.shape) == 4
         if self.ksize != 3 or self.padding != 1 or self.stride not in (1, 2):
             raise NotImplementedError("the HIP convolution implements ksize=3, padding=1, stride 1|2 "
                                       "(got ksize=%d padding=%d stride=%d)" % (self.ksize, self.padding, self.stride))
         w, slot = self.synthesize()
         if self.mode == "train":
+            if bn is not None:
+                return bn_relu_conv(bn, x, w, self.stride, slot, res, split)
             return _Conv3x3.apply(x, w, self.stride, slot, res)
+        xs = x
+        if bn is not None:
+            x = bn_relu(bn, x)
         y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], w["q"] if "q" in w else self.q_level.detach(), self.stride)
-        return y if res is None else y + res
+        y = y if res is None else y + res
+        return (y, xs) if split else y
 
 
 class QLinear(_QuantBase):
@@ -374,14 +436,12 @@ class _Block(nn.Module):
     def _residual_forward(self, x):
         """adp_qtz_fan.py:673-678.  bn1 hands x through for the shortcut so that the shortcut's gradient
         is added inside bn1's backward kernel; the shortcut itself is added inside conv2's kernel."""
-        out, xs = bn_relu(self.bn1, x, split=True)
-        out = bn_relu(self.bn2, self.conv1(out))
-        return self.conv2(out, res=self._apply_shortcut(xs))
+        out, xs = self.conv1(x, bn=self.bn1, split=True)
+        return self.conv2(out, res=self._apply_shortcut(xs), bn=self.bn2)
 
     def _preresidual_forward(self, x):
         """adp_qtz_fan.py:689-693"""
-        out = bn_relu(self.bn2, self.conv1(x))
-        return self.conv2(out, res=x)
+        return self.conv2(self.conv1(x), res=x, bn=self.bn2)
 
 
 class QResNet(nn.Module):

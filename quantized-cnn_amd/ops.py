@@ -406,3 +406,50 @@ def absmax(tensors):
     sizes = (C.c_longlong * n)(*[t.numel() for t in tensors])
     _lib.check(_lib.lib().aq_absmax(ptrs, sizes, n, _lib.ptr(out), _lib.stream()))
     return out
+
+
+# ------------------------------------------------- convolution that normalises its input while staging it
+
+_bnconv_ok = {}
+
+
+def bnconv_supported(x_shape, Cout, stride):
+    """True when conv(relu(batch_norm(x))) can run without materialising the activated tensor."""
+    key = (tuple(int(v) for v in x_shape), int(Cout), int(stride))
+    if key not in _bnconv_ok:
+        _bnconv_ok[key] = bool(_lib.lib().aq_bnconv_supported(*_conv_dims(x_shape, Cout, stride)))
+    return _bnconv_ok[key]
+
+
+def bnconv_forward(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, W, stride=1, res=None):
+    """y = conv3x3(relu(batch_norm(x)), W) [+ res] with batch statistics (adp_qtz_fan.py:674-677, 690-692);
+    returns (y, save_mean, save_rstd) and updates the running statistics like nn.BatchNorm2d."""
+    N, Cin, H, Wd = x.shape
+    y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride), dtype=torch.float32, device=x.device)
+    if res is not None and tuple(res.shape) != tuple(y.shape):
+        raise ValueError("bnconv_forward: res %s does not match the output %s" % (tuple(res.shape), tuple(y.shape)))
+    mean = torch.empty(Cin, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(Cin, dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().aq_bn_workspace_bytes(int(N), int(Cin), int(H * Wd))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_bnconv_fwd(
+        _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
+        _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), float(eps),
+        float(momentum), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd),
+        *_conv_dims(x.shape, W.shape[0], stride), ws.data_ptr(), nbytes, _lib.stream()))
+    return y, mean, rstd
+
+
+def bnconv_wgrad_partial(x, gamma, beta, save_mean, save_rstd, dy, stride=1):
+    """conv_wgrad_partial with relu(batch_norm(x)) recomputed from the saved statistics as the operand."""
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):
+        raise ValueError("bnconv_wgrad_partial: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    dims = _conv_dims(x.shape, Cout, stride)
+    nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    nslab = C.c_int(0)
+    _lib.check(_lib.lib().aq_bnconv_wgrad_partial(
+        _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(save_mean, name="save_mean"),
+        _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(dy, name="dy"), *dims, ws.data_ptr(), nbytes, C.byref(nslab), _lib.stream()))
+    return ws, nslab.value

@@ -27,5 +27,7 @@ for (cin, cout, s, H) in [(16, 16, 1, 32), (32, 32, 1, 16), (64, 64, 1, 8)]:
     x = torch.randn(N, cin, H, H, device="cuda"); W = torch.randn(cout, cin, 3, 3, device="cuda") * 0.1
     y = ops.conv_forward(x, W, s); dy = torch.randn_like(y)
     trace("fwd %d->%d %dx%d (us since first stamp)" % (cin, cout, H, H), lambda: ops.conv_forward(x, W, s), FW)
+    g_, b_ = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+    trace("bn+fwd", lambda: ops.bnconv_forward(x, g_, b_, None, None, None, 1e-5, 0.1, W, s), FW + [(7, "bn merged")])
     trace("dgrad", lambda: ops.conv_dgrad(dy, W, x.shape, s), FW)
     trace("wgrad", lambda: ops.conv_wgrad(x, dy, s), WG)

@@ -494,3 +494,41 @@ def test_bn_relu_with_fused_mean_pool(shape):
     pe = ops.bn_relu_forward(x, g, b, rm, rv, None, use_running_stats=True, pool=True)[0]
     ye = ops.bn_relu_forward(x, g, b, rm, rv, None, use_running_stats=True)[0]
     assert (pe.double() - ye.double().mean(dim=(2, 3))).abs().max().item() <= 1e-6 * max(1.0, ye.abs().max().item())
+
+
+# ------------------------------------------- convolution that normalises its input while staging it
+# Same operation sequence as the separate kernels (statistics merge, fma + max, MFMA accumulation order),
+# so results are bit-identical to bn_relu_forward followed by conv_forward / conv_wgrad.
+
+@pytest.mark.parametrize("shape", [(16, 16, 1, 32, 128), (16, 32, 2, 32, 128), (32, 32, 1, 16, 128), (32, 64, 2, 16, 128), (64, 64, 1, 8, 128),
+                                   (16, 16, 1, 32, 3), (64, 64, 1, 8, 2), (32, 32, 1, 16, 5)])
+def test_bnconv_equals_separate_kernels(shape):
+    cin, cout, s, H, N = shape
+    rs = np.random.RandomState(sum(shape))
+    x = cu(rs.standard_normal((N, cin, H, H)) * 1.3 + 0.2)
+    W = cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(cin)), cu(0.2 * rs.standard_normal(cin))
+    assert ops.bnconv_supported(x.shape, cout, s)
+    rm1, rv1, n1 = torch.zeros(cin, device=DEV), torch.ones(cin, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    rm2, rv2, n2 = rm1.clone(), rv1.clone(), n1.clone()
+    z, mean, rstd = ops.bn_relu_forward(x, g, b, rm1, rv1, n1)
+    y_ref = ops.conv_forward(z, W, s)
+    res = cu(rs.standard_normal(tuple(y_ref.shape)))
+    y, mean2, rstd2 = ops.bnconv_forward(x, g, b, rm2, rv2, n2, 1e-5, 0.1, W, s)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and int(n2) == 1
+    assert torch.equal(y, y_ref)
+    y2, _, _ = ops.bnconv_forward(x, g, b, None, None, None, 1e-5, 0.1, W, s, res=res)
+    assert torch.equal(y2, y_ref + res)
+    dy = cu(rs.standard_normal(tuple(y_ref.shape)))
+    ws, nslab = ops.bnconv_wgrad_partial(x, g, b, mean, rstd, dy, s)
+    dW = torch.empty_like(W)
+    ops.conv_wgrad_reduce([(ws, dW, nslab)])
+    assert torch.equal(dW, ops.conv_wgrad(z, dy, s))
+
+
+def test_bnconv_unsupported_shapes_are_reported():
+    assert not ops.bnconv_supported((2, 8, 40, 36), 80, 1)      # tiles narrower than the output
+    x = torch.zeros(2, 8, 40, 36, device=DEV)
+    with pytest.raises(RuntimeError, match="aq_bnconv_supported"):
+        ops.bnconv_forward(x, torch.ones(8, device=DEV), torch.zeros(8, device=DEV), None, None, None, 1e-5, 0.1,
+                           torch.zeros(80, 8, 3, 3, device=DEV), 1)
