@@ -222,6 +222,18 @@ int aq_augment_batch(const uint8_t *data, long long n_images, const int *index, 
  * pointers / element counts; out: device [n]. */
 int aq_absmax(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
 
+/* Tail of the step, `loss = criterion(logits, y) + model_loss(config, beta, model)` (adp_qtz_fan.py:288-289,
+ * criterion = nn.CrossEntropyLoss(), :202; model_loss :737-754):
+ * aq_sumsq: out[i] = sum of squares of tensor i (HOST arrays of n device pointers / sizes), one launch
+ *   per 32 tensors: the `torch.sum(param**2)` terms of the dense "weight" tensors.
+ * aq_ce_loss: logits [N, C] fp32, labels [N] int64 ->
+ *   out[0] = mean cross entropy, out[1] = l2_reg * (sum sumsq_a[0..na) + sum sumsq_b[0..nb)), out[2] = their sum;
+ *   dlogits [N, C] (may be NULL) = d out[0] / d logits = (softmax - onehot) / N.  A label outside [0, C)
+ *   makes out[0] NaN. */
+int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
+int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na,
+               const float *sumsq_b, int nb, float l2_reg, float *dlogits, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,6 +244,19 @@ def augment_batch(data, index, off_y, off_x, flip, pad=4, mean=(0.4915, 0.4821, 
     return out
 
 
+def ce_loss(logits, labels):
+    """nn.CrossEntropyLoss() (mean reduction, adp_qtz_fan.py:202, 288) and d loss / d logits, in float64."""
+    x = np.asarray(logits, np.float64)
+    y = np.asarray(labels, np.int64)
+    m = x.max(axis=1, keepdims=True)
+    lse = m + np.log(np.exp(x - m).sum(axis=1, keepdims=True))
+    n = x.shape[0]
+    loss = float((lse[:, 0] - x[np.arange(n), y]).mean())
+    d = np.exp(x - lse)
+    d[np.arange(n), y] -= 1.0
+    return loss, d / n
+
+
 def levels_fix(s, num_level, liar=True):
     """adp_qtz_fix.py:661-665: [-2^t .. descending magnitude], 0, [2^t ..]; num_level-1 entries."""
     import math

@@ -453,3 +453,33 @@ def bnconv_wgrad_partial(x, gamma, beta, save_mean, save_rstd, dy, stride=1):
         _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(save_mean, name="save_mean"),
         _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(dy, name="dy"), *dims, ws.data_ptr(), nbytes, C.byref(nslab), _lib.stream()))
     return ws, nslab.value
+
+
+# ------------------------------------------------------------------------------------- loss tail
+
+def sumsq(tensors):
+    """Sum of squares of every tensor in the list (one launch per 32 tensors) -> fp32 device tensor [n]:
+    the `torch.sum(param**2)` terms of model_loss (adp_qtz_fan.py:741-743)."""
+    n = len(tensors)
+    out = torch.empty(n, dtype=torch.float32, device=tensors[0].device)
+    ptrs = (C.c_void_p * n)(*[_lib.ptr(t, name="tensor[%d]" % i) for i, t in enumerate(tensors)])
+    sizes = (C.c_longlong * n)(*[t.numel() for t in tensors])
+    _lib.check(_lib.lib().aq_sumsq(ptrs, sizes, n, _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=True):
+    """CrossEntropyLoss (mean) + regulariser value in one launch (adp_qtz_fan.py:288-289):
+    -> (vals, dlogits) with vals = [ce, l2_reg*(sum sumsq_a + sum sumsq_b), their sum] on the device and
+    dlogits = d ce / d logits (None unless need_grad)."""
+    if logits.dim() != 2 or labels.shape != logits.shape[:1]:
+        raise ValueError("ce_loss: logits %s / labels %s" % (tuple(logits.shape), tuple(labels.shape)))
+    N, Cn = logits.shape
+    vals = torch.empty(3, dtype=torch.float32, device=logits.device)
+    d = torch.empty_like(logits) if need_grad else None
+    na = 0 if sumsq_a is None else sumsq_a.numel()
+    nb = 0 if sumsq_b is None else sumsq_b.numel()
+    _lib.check(_lib.lib().aq_ce_loss(_lib.ptr(logits, name="logits"), _lib.ptr(labels, torch.int64, "labels"), int(N), int(Cn),
+                                     _lib.ptr(sumsq_a, name="sumsq_a"), na, _lib.ptr(sumsq_b, name="sumsq_b"), nb, float(l2_reg),
+                                     _lib.ptr(d), _lib.ptr(vals), _lib.stream()))
+    return vals, d

@@ -78,8 +78,8 @@ class DataParallel:
                 flat.copy_(h)
             flat.div_(self.world)
         else:
-            # RCCL averages inside the collective: no separate scaling pass over the buffer
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.AVG, group=self.group)
+            self.dist.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
 
     def reduce_dense(self):
         if self.world == 1:
@@ -262,11 +262,15 @@ class FusedTrainStep:
             l._shared = (w, slot)
         self.model._synth_cache = None
         logits = self.model.forward_body(x)
-        ce = self.criterion(logits, y)
+        # loss tail in two launches: sums of squares of the dense "weight" tensors, then cross entropy, its
+        # gradient and the loss value (the regulariser's value enters here, its gradients in phase B:
+        # 2*l2_reg*w is added to the batch gradient after the exchange, being the same on every rank)
+        dense_ss = ops.sumsq([p.detach() for p in self.dense_reg]) if self.dense_reg else None
+        vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(self.config.l2_reg), out["sumsq"], dense_ss)
         jobs = []
         prev = layers.defer_wgrad_reductions(jobs, self._side if self.overlap_wgrad else None)
         try:
-            ce.backward()
+            logits.backward(dlogits)
         finally:
             layers.defer_wgrad_reductions(*prev)
         if self.overlap_wgrad:
@@ -278,12 +282,7 @@ class FusedTrainStep:
         if self._exchange:
             # dense gradients behind dW in the flat exchange buffer (one kernel)
             torch.cat([p.grad.reshape(-1) for p in self.dense], out=self.g_flat[self.nW:])
-        # the regulariser of the dense "weight" tensors enters the loss value here and the gradients in
-        # phase B (2*l2_reg*w added to the batch gradient, after the exchange: it is the same on every rank)
-        with torch.no_grad():
-            dense_sq = torch.stack(torch._foreach_norm(self.dense_reg)).pow(2).sum() if self.dense_reg else 0.0
-            self.reg = self.config.l2_reg * (dense_sq + out["sumsq"].sum())
-            self.loss = ce.detach() + self.reg
+        self.reg, self.loss = vals[1], vals[2]
         self.logits = logits.detach()
 
     def _phase_b(self):

@@ -532,3 +532,38 @@ def test_bnconv_unsupported_shapes_are_reported():
     with pytest.raises(RuntimeError, match="aq_bnconv_supported"):
         ops.bnconv_forward(x, torch.ones(8, device=DEV), torch.zeros(8, device=DEV), None, None, None, 1e-5, 0.1,
                            torch.zeros(80, 8, 3, 3, device=DEV), 1)
+
+
+# ------------------------------------------------------------------------------------ loss tail
+
+@pytest.mark.parametrize("shape", [(128, 10), (1, 10), (300, 7), (5, 1), (64, 100)])
+def test_ce_loss_and_sumsq_vs_oracle_and_torch(shape):
+    """fp32 exp/log against the float64 oracle: 2e-6 relative on the loss, 5e-7 absolute on the gradient
+    (entries are at most 1/N in magnitude)."""
+    rs = np.random.RandomState(sum(shape))
+    N, Cn = shape
+    x = (rs.standard_normal(shape) * 3).astype(np.float32)
+    y = rs.randint(0, Cn, N)
+    a = [cu(rs.standard_normal(n)) for n in (1, 5, 432, 16, 36864, 64)]
+    ssa = ops.sumsq(a)
+    for t, s in zip(a, ssa.tolist()):
+        assert abs(s - float((t.double() ** 2).sum())) <= 2e-6 * float((t.double() ** 2).sum())
+    ssb = cu(rs.uniform(0, 2, 19))
+    vals, d = ops.ce_loss(cu(x), torch.from_numpy(y).cuda(), 5e-4, ssa, ssb)
+    loss, dref = O.ce_loss(x, y)
+    ce, reg, tot = vals.tolist()
+    assert abs(ce - loss) <= 2e-6 * max(1.0, abs(loss))
+    want_reg = 5e-4 * (float(ssa.double().sum()) + float(ssb.double().sum()))
+    assert abs(reg - want_reg) <= 2e-6 * want_reg and abs(tot - (ce + reg)) <= 1e-6 * abs(tot)
+    assert np.abs(d.cpu().numpy() - dref).max() <= 5e-7
+    # the stock operator agrees
+    xt = cu(x).requires_grad_(True)
+    lt = torch.nn.functional.cross_entropy(xt, torch.from_numpy(y).cuda())
+    lt.backward()
+    assert abs(float(lt) - ce) <= 2e-6 * max(1.0, abs(ce)) and (xt.grad - d).abs().max().item() <= 5e-7
+    # value only; a label out of range poisons the loss
+    v2, d2 = ops.ce_loss(cu(x), torch.from_numpy(y).cuda(), need_grad=False)
+    assert d2 is None and v2[0].item() == ce and v2[1].item() == 0.0
+    bad = torch.from_numpy(y).cuda().clone()
+    bad[0] = Cn
+    assert np.isnan(ops.ce_loss(cu(x), bad)[0][0].item())
