@@ -6,8 +6,9 @@
 
 One "step" = one optimisation step of the quantized ResNet-20 (adp_qtz_fan flavour, 32 learned
 levels) on a synthetic CIFAR-10 shaped batch of 128 images per GPU: one synthesis launch for the 19
-quantized layers, forward, CrossEntropy + model_loss, backward (MFMA conv dgrad/wgrad + one synthesis
-gradient launch), three Adam updates.  Inputs are resident in HBM before the timed region.  Prints
+quantized layers, forward (MFMA convolutions, fused BatchNorm+ReLU kernels), CrossEntropy + model_loss,
+backward (conv dgrad/wgrad, BatchNorm backward, one synthesis-gradient launch with the Adam update of
+p_c fused in), Adam for the two small parameter groups.  Inputs are resident in HBM before the timed region.  Prints
 one JSON line (rank 0).  Extra objects on that line:
   roofline      the quantize kernel (weight-synthesis forward) on the standalone sweep tensor
                 (250 M primary coefficients, L=32): algorithmic bytes (132 B per weight row) / average
@@ -68,24 +69,33 @@ def kernel_rooflines(quick):
     t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 10)
     # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc on the same
     # 250 M-element tensor, see profiles/roofline_traffic.json); only valid for the full-size tensor
-    traffic = traffic2 = None
+    traffic = traffic2 = traffic3 = None
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tf) and not quick:
         try:
             tj = json.load(open(tf))
             if tj.get("rows_per_launch") == rows:
                 traffic, traffic2 = tj.get("synth_fwd_bytes_per_launch"), tj.get("synth_bwd_bytes_per_launch")
+                traffic3 = tj.get("synth_bwd_adam_bytes_per_launch")
         except Exception:
-            traffic = traffic2 = None
+            traffic = traffic2 = traffic3 = None
     a1 = rows * (4 * L + 4) / t1 / 1e9
     roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
-    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false, false>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": traffic2, "bytes_per_row": 8 * L + 4, "rows_per_launch": rows,
              "avg_launch_ms": round(t2 * 1e3, 4)}]
-    del p, dW, W, dp
+    # the same kernel with the Adam update of p_c fused in: p, m, v read and written, 24L+4 bytes per row
+    del dp
+    m1, m2, stp = torch.zeros_like(p), torch.zeros_like(p), torch.zeros((), device=dev)
+    t3 = event_time(lambda: ops.synth_backward_adam([p], [q], 4.0, [dW], [m1], [m2], [stp], 1e-2, wd=1e-3), 10)
+    a3 = rows * (24 * L + 4) / t3 / 1e9
+    more.append({"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false, true> (Adam update fused)", "achieved": round(a3, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 4), "traffic": traffic3, "bytes_per_row": 24 * L + 4,
+                 "rows_per_launch": rows, "avg_launch_ms": round(t3 * 1e3, 4)})
+    del p, dW, W, m1, m2
     torch.cuda.empty_cache()
     for (cin, cout, s, H) in [(16, 16, 1, 32), (16, 32, 2, 32), (32, 32, 1, 16), (32, 64, 2, 16), (64, 64, 1, 8)]:
         x = torch.randn(BATCH, cin, H, H, device=dev)

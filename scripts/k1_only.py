@@ -12,5 +12,9 @@ for _ in range(5):
     ops.synth_forward([p], [q], 4.0, out_W=W)
 for _ in range(5):
     ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp)
+del dp
+m1, m2, stp = torch.zeros_like(p), torch.zeros_like(p), torch.zeros((), device="cuda")
+for _ in range(5):
+    ops.synth_backward_adam([p], [q], 4.0, [dW], [m1], [m2], [stp], 1e-2, wd=1e-3)
 torch.cuda.synchronize()
-print("rows", rows, "alg bytes fwd", rows * 132, "bwd", rows * 260)
+print("rows", rows, "alg bytes fwd", rows * 132, "bwd", rows * 260, "bwd+adam", rows * 772)
