@@ -417,9 +417,10 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
     // so the 4 consecutive k of one row form one 16-byte LDS store.  Forward: work item = (row, group of
     // 4 k); all items of a thread are loaded before the first store (the fill is latency-bound).
     auto as_index = [&](int rl, int k) { return (((k >> 4) * MT + (rl >> 4)) * 64 + ((k >> 2) & 3) * 16 + (rl & 15)) * 4 + (k & 3); };
-    if (MODE == MODE_DGRAD) {
-        // A[row = ci, k = (co, tap)] = W[co, ci, 8 - tap]: work item = (co, row), whose nine taps are
-        // contiguous in memory; all loads of a round are issued before the first LDS store
+    if (MODE == MODE_DGRAD || MODE == MODE_FWD) {
+        // forward: A[row = co, k = (ci, tap)] = W[co, ci, tap];  dgrad: A[row = ci, k = (co, tap)] =
+        // W[co, ci, 8 - tap].  Work item = (channel c of the k axis, row), whose nine taps are contiguous in
+        // memory; all loads of a round are issued before the first LDS store
         const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(a.W, (unsigned)(a.Cout * a.Cin * 9) * 4u);
         const int items = 16 * MT * a.KC;
         for (int base = 0; base < items; base += 256 * 4) {
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                 const int it = base + u * 256 + tid;
                 const int c = it / (16 * MT), rl = it - c * (16 * MT);
                 const int row = m0 + rl;
-                const unsigned o = (it < items && row < a.M) ? (unsigned)((c * a.Cin + row) * 9) * 4u : BUF_OOB;
+                const unsigned o = (it < items && row < a.M) ? (unsigned)((MODE == MODE_DGRAD ? c * a.Cin + row : row * a.Cin + c) * 9) * 4u
+                                                             : BUF_OOB;
 #pragma unroll
                 for (int tw = 0; tw < 9; ++tw) w[u][tw] = buf_load(wsrc, o + 4u * tw, 0);
             }
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                 const int c = it / (16 * MT), rl = it - c * (16 * MT);
                 if (it < items) {
 #pragma unroll
-                    for (int tw = 0; tw < 9; ++tw) As[as_index(rl, c * 9 + 8 - tw)] = w[u][tw];
+                    for (int tw = 0; tw < 9; ++tw) As[as_index(rl, c * 9 + (MODE == MODE_DGRAD ? 8 - tw : tw))] = w[u][tw];
                 }
             }
         }
