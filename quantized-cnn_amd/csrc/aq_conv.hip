@@ -630,6 +630,7 @@ struct WgradArgs {
     int TW, TH, tiles_x, tiles_y;
     int pitch, rows_in, plane;   // LDS image of x
     int cpitch;                  // LDS pitch of a dy channel (TH*TW + 2)
+    int CW;                      // input channels a workgroup stages: those its (ci, tap) columns touch
     int tw_shift, npix_shift;    // TW and TH*TW are powers of two
     int pitch_mul;               // e / pitch == (e * pitch_mul) >> 16 for e < 1024, pitch <= 65
     int IPB;                     // images per workgroup
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int npix = a.TH * a.TW;
-    const int bufsz = 16 * MG * a.cpitch + a.Cin * a.plane;  // floats per buffer: dy tile, then x image
+    const int bufsz = 16 * MG * a.cpitch + a.CW * a.plane;  // floats per buffer: dy tile, then x image
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const bool loader = threadIdx.x >= 256;
@@ -662,6 +663,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int m0 = blockIdx.y * 16 * MG;   // first output channel of this group
     const int j0 = blockIdx.z * 16 * NG;   // first (ci, tap) column of this group
+    const int c_lo = j0 / 9;               // first input channel those columns touch
+    const int ceff = min(a.Cin - c_lo, a.CW);  // channels staged by this workgroup
 
     // compute wavefronts: column (ci, tap) owned by this lane in each n-tile -> offset inside the x image
     int joff[NG];
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
         int off = 0;
         if (jcol < a.K9) {
             const int ci = jcol / 9, tap = jcol - 9 * ci;
-            off = ci * a.plane + (tap / 3) * a.pitch + (tap % 3);
+            off = (ci - c_lo) * a.plane + (tap / 3) * a.pitch + (tap % 3);
         }
         joff[g] = off;
     }
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
         for (int u = 0; u < 8 * MG; ++u) dvr[u] = buf_load(sdy, dvo[u], 0);
 #pragma unroll
         for (int u = 0; u < CH4R; ++u) {
-            const int c = min(wave_s + 4 * u, a.Cin - 1);  // channels beyond Cin are never committed
+            const int c = c_lo + min(wave_s + 4 * u, ceff - 1);  // slots beyond the staged channels are never committed
             const unsigned soff = (unsigned)(c * xchs) * 4u;
 #pragma unroll
             for (int j = 0; j < JR; ++j) sv[u][j] = buf_load(sx, xvo[j], soff);
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     if (CH4 > 0 && loader && a.bn_mean) {
 #pragma unroll
         for (int u = 0; u < CH4R; ++u) {
-            const int c = min(wave_s + 4 * u, a.Cin - 1);
+            const int c = c_lo + min(wave_s + 4 * u, ceff - 1);
             scale_shift(a.bn_gamma[c], a.bn_beta[c], a.bn_mean[c], a.bn_rstd[c], wsc[u], wsh[u]);
         }
     }
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             for (int j = 0; j < JR; ++j) {
                 float v = sv[u][j];
                 if (a.bn_mean) v = xvo[j] != BUF_OOB ? fmaxf(__builtin_fmaf(v, wsc[u], wsh[u]), 0.0f) : 0.0f;  // padding stays 0
-                if (c < a.Cin && xin[j]) xs[c * a.plane + lane + 64 * j] = v;
+                if (c < ceff && xin[j]) xs[c * a.plane + lane + 64 * j] = v;
             }
         }
     };
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
             const int co = m0 + c;
             dvA[u] = (c < 16 * MG && poff >= 0 && co < a.Cout) ? src[(long long)co * chs + poff] : 0.0f;
         }
-        stage_image(xs, a.x + (long long)n * a.Cin * a.H * a.Wd, a.Cin, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
+        stage_image(xs, a.x + ((long long)n * a.Cin + c_lo) * a.H * a.Wd, ceff, a.H, a.Wd, a.plane, a.pitch, r0, c0, 1, tid);
 #pragma unroll
         for (int u = 0; u < 8 * MG; ++u) {
             const int c = (tid >> a.npix_shift) + cstep * u;
@@ -1264,11 +1267,19 @@ static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &ld
     a.pitch = (a.TW - 1) * a.stride + 3;
     a.rows_in = (a.TH - 1) * a.stride + 3;
     a.plane = a.rows_in * a.pitch;
+    {   // channels touched by the 16*NG consecutive (ci, tap) columns of one workgroup
+        const int gzs = (ntiles + NG - 1) / NG;
+        a.CW = 1;
+        for (int z = 0; z < gzs; ++z) {
+            const int j0 = z * 16 * NG, j1 = std::min(a.K9, j0 + 16 * NG) - 1;
+            a.CW = std::max(a.CW, j1 / 9 - j0 / 9 + 1);
+        }
+    }
     {   // pad the LDS image against bank conflicts when that keeps the per-lane element count (the kernel
         // variants are instantiated per count) and the LDS budget
         int pp = a.pitch, pl = a.plane;
         wgrad_pad(a.stride, a.K9, a.rows_in, pp, pl);
-        const size_t need = 2 * ((size_t)16 * MG * (a.TH * a.TW + 2) + (size_t)a.Cin * pl) * 4;
+        const size_t need = 2 * ((size_t)16 * MG * (a.TH * a.TW + 2) + (size_t)a.CW * pl) * 4;
         if ((pl + 63) / 64 == (a.plane + 63) / 64 && need <= 160 * 1024) { a.pitch = pp; a.plane = pl; }
     }
     a.cpitch = a.TH * a.TW + 2;
@@ -1286,7 +1297,7 @@ static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &ld
     const long long gx = (long long)a.ngroups_img * a.tiles_x * a.tiles_y;
     AQ_REQUIRE(gx < (1LL << 31) && gy < 65536 && gz < 65536, -E2BIG, "aq_conv_wgrad: grid too large");
     grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)gz);
-    lds = 2 * ((size_t)16 * MG * a.cpitch + (size_t)a.Cin * a.plane) * 4;  // two chunk buffers
+    lds = 2 * ((size_t)16 * MG * a.cpitch + (size_t)a.CW * a.plane) * 4;  // two chunk buffers
     lds = std::max(lds, (size_t)8 * 4 * 256 * 4);
     AQ_REQUIRE(lds <= 160 * 1024, -E2BIG, "aq_conv_wgrad: tiles need %zu bytes of LDS (limit 163840): too many channels", lds);
     ws_bytes = (size_t)gx * a.Cout * a.K9 * 4;
@@ -1309,14 +1320,14 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
 // and the image must fit the staging budget
 static int wgrad_variant(const aq::WgradArgs &a, int MG, int NG)
 {
-    const int c4 = (a.Cin + 3) / 4, jx = (a.plane + 63) / 64;
+    const int c4 = (a.CW + 3) / 4, jx = (a.plane + 63) / 64;
     const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
     if (a.tiles_x != 1 || !fits32) return 0;
     if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) return 1;
     if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) return 2;
+    if (NG == 18 && c4 <= 8 && jx <= 2) return 5;  // 18 n-tiles = 288 columns = at most 32 channels
     if (NG == 18 && c4 <= 8 && jx <= 3) return 3;
     if (NG == 18 && c4 <= 8 && jx <= 5) return 4;
-    if (NG == 18 && c4 <= 16 && jx <= 2) return 5;
     return 0;
 }
 
@@ -1472,7 +1483,7 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     else if (variant == 2) AQ_WGV(2, 9, 4, 9)
     else if (variant == 3) AQ_WGV(1, 18, 8, 3)
     else if (variant == 4) AQ_WGV(1, 18, 8, 5)
-    else if (variant == 5) AQ_WGV(1, 18, 16, 2)
+    else if (variant == 5) AQ_WGV(1, 18, 8, 2)
     else if (NG == 3) AQ_WG(1, 3)
     else if (NG == 9 && MG == 1) AQ_WG(1, 9)
     else if (NG == 9) AQ_WG(2, 9)
