@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 4
+#define AQ_ABI_VERSION 5
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -93,6 +93,22 @@ int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H,
  * shape of y and may alias it. */
 int aq_conv_fwd_add(const float *x, const float *W, const float *res, float *y, int N, int Cin, int H,
                     int Wd, int Cout, int ksize, int stride, int pad, void *stream);
+/* aq_conv_fwd / aq_conv_fwd_add (res may be NULL) that also leaves the channel statistics of y behind for
+ * the batch normalisation that consumes y next (`self.bnK(...)` after every convolution,
+ * adp_qtz_fan.py:674-675, 690, 726, 730): every workgroup writes (mean, M2) of the pixels it produced, per
+ * output channel, into `stats` ([Cout][desc->P] pairs; aq_conv_stats_bytes bytes), and *desc says how the
+ * tiles were shared out.  aq_bn_relu_fwd / aq_bn_relu_pool_fwd take the pair (stats, desc) in place of
+ * their own statistics pass over y.  aq_conv_stats_bytes == 0: this shape has no such epilogue (-ENOTSUP
+ * from aq_conv_fwd_stats); use aq_conv_fwd and the plain batch normalisation. */
+typedef struct aq_conv_stats {
+    int32_t P;       /* partials per channel (workgroups of the convolution) */
+    int32_t ntiles;  /* workgroup w produced tiles w, w + P, w + 2P, .. < ntiles */
+    int32_t tile_px; /* output pixels per tile */
+} aq_conv_stats;
+size_t aq_conv_stats_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad);
+int aq_conv_fwd_stats(const float *x, const float *W, const float *res, float *y, int N, int Cin, int H,
+                      int Wd, int Cout, int ksize, int stride, int pad, void *stats, size_t stats_bytes,
+                      aq_conv_stats *desc, void *stream);
 /* same, weights given as codes + levels (hard mode, adp_qtz_fan_test.py:304-331): W = q[idx] is
  * decoded while the weight tile is staged into LDS. */
 int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L, float *y, int N,
@@ -137,13 +153,15 @@ int aq_linear_bwd(const float *x, const float *W, const float *dy, float *dx, fl
  * pass and, when running_mean / running_var are given, updates them as nn.BatchNorm2d does
  * (r += momentum*(batch - r), unbiased variance; *num_batches_tracked += 1 when non-NULL).
  * AQ_BN_EVAL: normalise with the running statistics instead (save_*, workspace unused).
- * workspace: aq_bn_workspace_bytes(N, C, HW) bytes. */
+ * workspace: aq_bn_workspace_bytes(N, C, HW) bytes.
+ * conv_stats != NULL (batch-statistics mode): x was written by aq_conv_fwd_stats and `workspace` is that
+ * call's `stats` buffer, *conv_stats its descriptor; the statistics pass over x is skipped. */
 #define AQ_BN_RELU 1u
 #define AQ_BN_EVAL 2u
 int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                    float *running_var, long long *num_batches_tracked, int N, int C, int HW, float eps,
                    float momentum, unsigned flags, float *y, float *save_mean, float *save_rstd,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats, void *stream);
 /* Gradient of the above in batch-statistics mode: dy is d loss / d y; dx = d loss / d x [+ res when
  * res != NULL: the gradient arriving over the block's shortcut, `out + x` adp_qtz_fan.py:677, 692],
  * dgamma[C], dbeta[C] (either may be NULL).  x, gamma, beta must be unchanged since the forward call
@@ -159,7 +177,7 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
 int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                         float *running_var, long long *num_batches_tracked, int N, int C, int HW, float eps,
                         float momentum, unsigned flags, float *pooled, float *save_mean, float *save_rstd,
-                        void *workspace, size_t workspace_bytes, void *stream);
+                        void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats, void *stream);
 int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_rstd, int N, int C, int HW, unsigned flags,
                         float *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -23,6 +23,7 @@ EXPORTS = (
     "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
+    "aq_conv_stats_bytes", "aq_conv_fwd_stats",
 )
 
 
@@ -33,6 +34,10 @@ class AqSeg(C.Structure):
         ("dW", C.c_void_p), ("dsumsq", C.c_void_p), ("dp_c", C.c_void_p), ("dq", C.c_void_p),
         ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_void_p),
     ]
+
+
+class AqConvStats(C.Structure):
+    _fields_ = [("P", C.c_int32), ("ntiles", C.c_int32), ("tile_px", C.c_int32)]
 
 
 class AqWgradJob(C.Structure):
@@ -71,7 +76,11 @@ def lib():
         L.aq_conv_wgrad_workspace_bytes.restype = sz
         L.aq_linear_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
         L.aq_linear_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp]
-        L.aq_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, f, C.c_uint, vp, vp, vp, vp, sz, vp]
+        L.aq_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, f, C.c_uint, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp]
+        L.aq_conv_stats_bytes.argtypes = conv_dims
+        L.aq_conv_stats_bytes.restype = sz
+        L.aq_conv_fwd_stats.argtypes = [vp, vp, vp, vp] + conv_dims + [vp, sz, C.POINTER(AqConvStats), vp]
+        L.aq_conv_fwd_stats.restype = i
         L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, vp]
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]

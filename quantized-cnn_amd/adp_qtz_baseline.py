@@ -21,8 +21,8 @@ def _conv(conv, x, res=None, bn=None, split=False):
     is the input; split: also return x for the caller's shortcut."""
     if _ours(conv, x):
         if bn is not None:
-            return layers.bn_relu_conv(bn, x, conv.weight, conv.stride[0], None, res, split)
-        return layers._Conv3x3.apply(x, conv.weight, conv.stride[0], None, res)
+            return layers.bn_relu_conv(bn, x, conv.weight, conv.stride[0], None, res, split, stats=conv.training)
+        return layers.conv3x3(x, conv.weight, conv.stride[0], None, res, stats=conv.training)
     xs = x
     if bn is not None:
         x = layers.bn_relu(bn, x)

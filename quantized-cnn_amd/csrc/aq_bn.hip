@@ -276,7 +276,8 @@ size_t aq_bn_workspace_bytes(int N, int C, int HW)
 
 static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                        long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
-                       float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream, bool pool)
+                       float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream,
+                       bool pool)
 {
     using namespace aq;
     const bool eval = flags & AQ_BN_EVAL, relu = flags & AQ_BN_RELU;
@@ -284,11 +285,24 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
     AQ_REQUIRE(x && gamma && beta && y, -EFAULT, "aq_bn_relu_fwd: NULL pointer");
     AQ_REQUIRE(eps >= 0.0f, -EINVAL, "aq_bn_relu_fwd: negative eps");
     AQ_REQUIRE((flags & ~(AQ_BN_RELU | AQ_BN_EVAL)) == 0, -EINVAL, "aq_bn_relu_fwd: unknown flags 0x%x", flags);
-    const BnGeom g = bn_geom(N, C, HW);
+    BnGeom g = bn_geom(N, C, HW);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(y);
     if (eval) {
         AQ_REQUIRE(running_mean && running_var, -EFAULT, "aq_bn_relu_fwd: evaluation mode needs the running statistics");
+    } else if (cs) {
+        AQ_REQUIRE(save_mean && save_rstd, -EFAULT, "aq_bn_relu_fwd: NULL save_mean / save_rstd");
+        AQ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), -EINVAL, "aq_bn_relu_fwd: running_mean and running_var go together");
+        AQ_REQUIRE(cs->P >= 1 && cs->P <= 64 * BN_CONV_PER_LANE && cs->ntiles >= cs->P && cs->tile_px >= 1 &&
+                       (long long)cs->ntiles * cs->tile_px == (long long)N * HW,
+                   -EINVAL, "aq_bn_relu_fwd: convolution statistics (P=%d, %d tiles of %d pixels) do not describe %d x %d values per channel",
+                   cs->P, cs->ntiles, cs->tile_px, N, HW);
+        AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * cs->P * sizeof(float2), -ENOSPC,
+                   "aq_bn_relu_fwd: convolution statistics take %zu bytes, %zu given", (size_t)C * cs->P * sizeof(float2), workspace_bytes);
+        g.P = cs->P;
+        g.pbase = cs->ntiles / cs->P;
+        g.prem = cs->ntiles % cs->P;
+        g.tile_px = cs->tile_px;
     } else {
         AQ_REQUIRE(save_mean && save_rstd, -EFAULT, "aq_bn_relu_fwd: NULL save_mean / save_rstd");
         AQ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), -EINVAL, "aq_bn_relu_fwd: running_mean and running_var go together");
@@ -314,18 +328,19 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
 
 int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                    long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
-                   float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+                   float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats, void *stream)
 {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, flags, y, save_mean, save_rstd,
-                       workspace, workspace_bytes, stream, false);
+                       workspace, workspace_bytes, conv_stats, stream, false);
 }
 
 int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                         long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *pooled,
-                        float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, void *stream)
+                        float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats,
+                        void *stream)
 {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, flags, pooled, save_mean,
-                       save_rstd, workspace, workspace_bytes, stream, true);
+                       save_rstd, workspace, workspace_bytes, conv_stats, stream, true);
 }
 
 static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, const float *gamma, const float *beta, const float *save_mean,

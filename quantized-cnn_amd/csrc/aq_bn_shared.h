@@ -14,11 +14,14 @@ struct BnGeom {
     int N, C, HW;
     int S, npb;    // reduction launches: S blocks per channel, npb images per block
     int S2, npb2;  // streaming launches
+    // statistics left behind by the producing convolution instead of the statistics pass (P > 0): partial
+    // w of P covers pbase (+1 when w < prem) tiles of tile_px pixels
+    int P, pbase, prem, tile_px;
 };
 
 inline BnGeom bn_geom(int N, int C, int HW)
 {
-    BnGeom g{N, C, HW, 1, 1, 1, 1};
+    BnGeom g{N, C, HW, 1, 1, 1, 1, 0, 0, 0, 0};
     int npb = HW >= 2048 ? 1 : 2048 / HW;
     g.npb2 = npb;
     g.S2 = (N + npb - 1) / npb;
@@ -109,8 +112,52 @@ __device__ inline void bn_channel_stats_multi(const BnStatsIn &a, const BnGeom &
     }
 }
 
+// The same merge over the P <= 512 partials of a convolution's epilogue (part[c * P + w], counts from the tile
+// distribution): lane l holds partials l, l + 64, ..; all loads are issued before the first reduction.
+constexpr int BN_CONV_PER_LANE = 8;
+__device__ inline void bn_channel_stats_conv(const BnStatsIn &a, const BnGeom &g, int c, int lane, bool writer, float &mean, float &rstd)
+{
+    float2 p[BN_CONV_PER_LANE];
+    float nw[BN_CONV_PER_LANE];
+#pragma unroll
+    for (int u = 0; u < BN_CONV_PER_LANE; ++u) {
+        const int w = lane + 64 * u;
+        const bool on = w < g.P;
+        p[u] = on ? a.part[c * g.P + w] : make_float2(0.0f, 0.0f);
+        nw[u] = on ? (float)((g.pbase + (w < g.prem ? 1 : 0)) * g.tile_px) : 0.0f;
+    }
+    const float cnt = (float)g.N * (float)g.HW;
+    const float rcnt = 1.0f / cnt;
+    float sm = 0.0f;
+#pragma unroll
+    for (int u = 0; u < BN_CONV_PER_LANE; ++u) sm = __builtin_fmaf(nw[u], p[u].x, sm);
+    mean = wave_sum(sm) * rcnt;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < BN_CONV_PER_LANE; ++u) {
+        const float d = p[u].x - mean;
+        m2 += __builtin_fmaf(nw[u] * d, d, p[u].y);
+    }
+    const float M2 = wave_sum(m2);
+    rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(M2, rcnt, a.eps));
+    if (writer && lane == 0) {
+        const float runb = 1.0f / fmaxf(cnt - 1.0f, 1.0f);
+        a.save_mean[c] = mean;
+        a.save_rstd[c] = rstd;
+        if (a.running_mean) {
+            a.running_mean[c] = __builtin_fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
+            a.running_var[c] = __builtin_fmaf(a.momentum, M2 * runb - a.running_var[c], a.running_var[c]);
+        }
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    }
+}
+
 __device__ inline void bn_channel_stats(const BnStatsIn &a, const BnGeom &g, int c, int lane, bool writer, float &mean, float &rstd)
 {
+    if (g.P > 0) {
+        bn_channel_stats_conv(a, g, c, lane, writer, mean, rstd);
+        return;
+    }
     const int cs[1] = {c};
     float m[1], r[1];
     bn_channel_stats_multi<1>(a, g, cs, lane, writer, m, r);

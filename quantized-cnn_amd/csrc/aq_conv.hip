@@ -88,6 +88,9 @@ struct ConvArgs {
     int bn_on;
     BnStatsIn bn;
     BnGeom bng;
+    // forward, persistent kernel only: per-workgroup (mean, M2) of every output channel over the pixels the
+    // workgroup produced, [M][gridDim.x]; the consumer is the batch normalisation that follows (NULL: off)
+    float2 *stat_part;
     int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
 };
 
@@ -303,6 +306,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
                 }
             }
         }
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), the same bits in each of them
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v = v + bn_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + bn_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + bn_dpp<0x141>(v);  // row_half_mirror
+    v = v + bn_dpp<0x140>(v);  // row_mirror
+    return v;
 }
 
 // Persistent variant of the forward / dgrad GEMM for tiles that span the whole output width
@@ -533,6 +546,14 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
     };
 
+    // channel statistics of the output (stat_part): every lane sums the values it stores, over all tiles
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.0f;
+    const bool stats_on = MODE != MODE_DGRAD && a.stat_part != nullptr;
+
     AQ_STAMP(2);
     int tcount_ = 0;
     for (; tile < ntiles; tile += gridDim.x) {
@@ -609,11 +630,43 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                     float v = acc[m][nt][r];
                     if (a.res) v += buf_load(rsd, o, 0);
                     buf_store(v, dst, o, 0);
+                    if (stats_on) {  // the host enables this for exact tilings only: every pixel is an output
+                        ssum[m][r] += v;
+                        ssq[m][r] = __builtin_fmaf(v, v, ssq[m][r]);
+                    }
                 }
         }
         __syncthreads();  // every wavefront is done with this tile's LDS image
         if (tcount_ == 0) AQ_STAMP(5);
         ++tcount_;
+    }
+    if (stats_on) {
+        // lanes of a 16-lane row share their channels: row sums by DPP, the four wavefronts through LDS
+        // (the weight panel is no longer needed), then one thread per channel in fixed order
+        float *red = As;  // [4 wavefronts][16*MT channels][2]
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(ssum[m][r]), s2 = row16_sum(ssq[m][r]);
+                if (jn == 0) {
+                    const int cl = 16 * m + 4 * kq + r;
+                    red[(wave * 16 * MT + cl) * 2] = s1;
+                    red[(wave * 16 * MT + cl) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 16 * MT && m0 + tid < a.M) {
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s1 += red[(w * 16 * MT + tid) * 2];
+                s2 += red[(w * 16 * MT + tid) * 2 + 1];
+            }
+            const float cnt = (float)(tcount_ * a.TH * a.TW);
+            const float mean = s1 / cnt;
+            a.stat_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(mean, fmaxf(__builtin_fmaf(-s1, mean, s2), 0.0f));
+        }
     }
     AQ_STAMP(6);
 }
@@ -1047,10 +1100,18 @@ static void pick_tile(int OW, int npix, int &TW, int &TH)
     TH = npix / TW;
 }
 
+// Partials of the output-channel statistics a forward launch leaves behind: workgroup w of P covered the tiles
+// w, w + P, .. of ntiles, tile_px pixels each (P == 0: this shape has no statistics epilogue).
+struct ConvStatsPlan {
+    int P, ntiles, tile_px;
+};
+constexpr int CONV_STATS_MAX_PARTS = 512;  // the consumer keeps ceil(P / 64) partials per lane in registers
+
 // dry: no launch; returns 1 when the persistent kernel (the one that can normalise its input) would run
 template <int MODE>
-static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false)
+static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false, ConvStatsPlan *plan = nullptr)
 {
+    if (plan) *plan = ConvStatsPlan{0, 0, 0};
     // tile choice: NT = 2 (128 pixels) and MT up to 4, shrunk until the grid fills the chip
     const int mtiles = (a.M + 15) / 16;
     int MT = std::min(4, mtiles), NT = 2;
@@ -1099,7 +1160,12 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         const int c4 = CH4 <= 4 ? 4 : (CH4 <= 8 ? 8 : 16);
         const int jj = J <= 2 ? 2 : (J <= 3 ? 3 : (J <= 5 ? 5 : 9));
         bool done = true;
-        if (dry) return ((jj == 5 && c4 > 8) || (jj == 9 && c4 > 4)) ? 0 : 1;
+        const bool have = !((jj == 5 && c4 > 8) || (jj == 9 && c4 > 4));
+        // statistics epilogue: every pixel of every tile is an output pixel, and few enough partials
+        const bool stats_ok = have && a.TW == a.OW && a.OH % a.TH == 0 && pgrid.x <= (unsigned)CONV_STATS_MAX_PARTS;
+        if (plan && stats_ok) *plan = ConvStatsPlan{(int)pgrid.x, (int)gx, a.TH * a.TW};
+        if (dry) return have ? 1 : 0;
+        AQ_REQUIRE(!a.stat_part || stats_ok, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
 #define AQ_P(MM, NN, CC, JJ)                                                                                                      \
     {                                                                                                                             \
         auto kern = conv_gemm_persist_kernel<MM, NN, CC, JJ, MODE>;                                                               \
@@ -1129,6 +1195,7 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
     }
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
+    AQ_REQUIRE(!a.stat_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
     dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
     if (MT == 4 && NT == 2) AQ_GEMM(4, 2);
@@ -1141,19 +1208,26 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
     return check_launch(who);
 }
 
+static void conv_fwd_args(ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride)
+{
+    a.N = N; a.Cin = Cin; a.Cout = Cout;
+    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
+}
+
 static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, const float *q, int L, const float *res, float *y, int N, int Cin,
-                           int H, int Wd, int Cout, int ks, int stride, int pad, hipStream_t st, const char *who)
+                           int H, int Wd, int Cout, int ks, int stride, int pad, hipStream_t st, const char *who, float2 *stat_part = nullptr,
+                           ConvStatsPlan *plan = nullptr)
 {
     if (int rc = check_conv(who, N, Cin, H, Wd, Cout, ks, stride, pad)) return rc;
     if (N == 0) return 0;
     AQ_REQUIRE(x && y && (W || (idx && q)), -EFAULT, "%s: NULL pointer", who);
     ConvArgs a = {};
     a.in = x; a.W = W; a.idx = idx; a.q = q; a.L = L; a.out = y; a.res = res;
-    a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
-    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
-    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
-    return idx ? launch_gemm<MODE_FWD_CODES>(a, N, st, who) : launch_gemm<MODE_FWD>(a, N, st, who);
+    a.stat_part = stat_part;
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
+    return idx ? launch_gemm<MODE_FWD_CODES>(a, N, st, who, false, plan) : launch_gemm<MODE_FWD>(a, N, st, who, false, plan);
 }
 
 } // namespace aq
@@ -1178,6 +1252,35 @@ int aq_conv_fwd_add(const float *x, const float *W, const float *res, float *y, 
     AQ_REQUIRE(res || N == 0, -EFAULT, "aq_conv_fwd_add: NULL res");
     return aq::conv_fwd_common(x, W, nullptr, nullptr, 0, res, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream),
                                "aq_conv_fwd_add");
+}
+
+size_t aq_conv_stats_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
+{
+    using namespace aq;
+    if (check_conv("aq_conv_stats_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
+    ConvArgs a = {};
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
+    ConvStatsPlan plan;
+    launch_gemm<MODE_FWD>(a, N, nullptr, "aq_conv_stats_bytes", true, &plan);
+    return (size_t)plan.P * Cout * sizeof(float2);
+}
+
+int aq_conv_fwd_stats(const float *x, const float *W, const float *res, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
+                      int pad, void *stats, size_t stats_bytes, aq_conv_stats *desc, void *stream)
+{
+    using namespace aq;
+    AQ_REQUIRE(desc, -EFAULT, "aq_conv_fwd_stats: NULL desc");
+    *desc = aq_conv_stats{0, 0, 0};
+    AQ_REQUIRE(N >= 1, -EINVAL, "aq_conv_fwd_stats: statistics of an empty batch");
+    const size_t need = aq_conv_stats_bytes(N, Cin, H, Wd, Cout, ksize, stride, pad);
+    AQ_REQUIRE(need > 0, -ENOTSUP, "aq_conv_fwd_stats: no statistics epilogue for this shape (aq_conv_stats_bytes is 0): run the separate statistics pass");
+    AQ_REQUIRE(stats && stats_bytes >= need, -ENOSPC, "aq_conv_fwd_stats: statistics buffer of %zu bytes needed, %zu given", need, stats_bytes);
+    ConvStatsPlan plan;
+    if (int rc = conv_fwd_common(x, W, nullptr, nullptr, 0, res, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream),
+                                 "aq_conv_fwd_stats", static_cast<float2 *>(stats), &plan))
+        return rc;
+    *desc = aq_conv_stats{plan.P, plan.ntiles, plan.tile_px};
+    return 0;
 }
 
 int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize,

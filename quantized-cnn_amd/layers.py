@@ -117,11 +117,15 @@ class _Conv3x3(torch.autograd.Function):
     """y = conv3x3(x, W) [+ res]; the gradient of res is dy itself."""
 
     @staticmethod
-    def forward(ctx, x, W, stride, dW_slot, res):
+    def forward(ctx, x, W, stride, dW_slot, res, holder=None):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
         ctx.stride, ctx.dW_slot = stride, dW_slot
-        return ops.conv_forward(x, W, stride, res.contiguous() if res is not None else None)
+        res = res.contiguous() if res is not None else None
+        if holder is None:
+            return ops.conv_forward(x, W, stride, res)
+        y, holder["stats"] = ops.conv_forward(x, W, stride, res, stats=True)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -142,7 +146,33 @@ class _Conv3x3(torch.autograd.Function):
                 _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
             else:
                 dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot)
-        return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None)
+        return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None), None
+
+
+# The convolution's epilogue can leave the channel statistics of its output behind, so that the batch
+# normalisation consuming that output skips its own statistics pass (one launch less per layer).  The
+# statistics travel as an attribute of the output tensor, together with the tensor's version counter: a
+# consumer only trusts them when the tensor has not been written to since.
+CONV_EMITS_BN_STATS = True
+_STATS_ATTR = "_aq_conv_stats"
+
+
+def conv3x3(x, W, stride, dW_slot, res=None, stats=False):
+    """_Conv3x3 on (x, W); stats=True asks the kernel for the output's channel statistics as well."""
+    if not (stats and CONV_EMITS_BN_STATS):
+        return _Conv3x3.apply(x, W, stride, dW_slot, res)
+    holder = {}
+    y = _Conv3x3.apply(x, W, stride, dW_slot, res, holder)
+    if holder.get("stats") is not None:
+        setattr(y, _STATS_ATTR, (holder["stats"], y._version))
+    return y
+
+
+def _stats_of(x):
+    tag = getattr(x, _STATS_ATTR, None)
+    if tag is None or tag[1] != x._version or not x.is_contiguous():
+        return None
+    return tag[0]
 
 
 class _BnRelu(torch.autograd.Function):
@@ -151,10 +181,10 @@ class _BnRelu(torch.autograd.Function):
     the backward kernel instead of by a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, relu, split, pool=False):
+    def forward(ctx, x, gamma, beta, bn, relu, split, pool=False, conv_stats=None):
         x = x.contiguous()
         z, mean, rstd = ops.bn_relu_forward(x, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                                            bn.momentum, relu=relu, pool=pool)
+                                            bn.momentum, relu=relu, pool=pool, conv_stats=conv_stats)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.relu, ctx.pool = relu, pool
         return (z, x.view_as(x)) if split else z
@@ -166,7 +196,7 @@ class _BnRelu(torch.autograd.Function):
             dz = torch.zeros((x.shape[0], x.shape[1]) if ctx.pool else x.shape, dtype=x.dtype, device=x.device)
         dx, dg, db = ops.bn_relu_backward(dz.contiguous(), x, gamma, beta, mean, rstd, res=dres.contiguous() if dres is not None else None,
                                           relu=ctx.relu, pool=ctx.pool)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
 
 
 def bn_relu_pool(bn, pool, x):
@@ -177,7 +207,7 @@ def bn_relu_pool(bn, pool, x):
     whole = (isinstance(pool, nn.AvgPool2d) and x.dim() == 4 and tuple(ks) == tuple(x.shape[2:]) and pool.padding in (0, (0, 0))
              and x.is_cuda and x.dtype == torch.float32 and bn.weight is not None)
     if whole and (bn.training or bn.running_mean is None) and bn.momentum is not None:
-        return _BnRelu.apply(x, bn.weight, bn.bias, bn, True, False, True).view(x.shape[0], x.shape[1], 1, 1)
+        return _BnRelu.apply(x, bn.weight, bn.bias, bn, True, False, True, _stats_of(x)).view(x.shape[0], x.shape[1], 1, 1)
     if whole and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
         y = ops.bn_relu_forward(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps, 0.0, relu=True,
                                 use_running_stats=True, pool=True)[0]
@@ -226,7 +256,7 @@ class _BnReluConv(torch.autograd.Function):
 FUSE_BN_INTO_CONV = False
 
 
-def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False):
+def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
     """conv(relu(bn(x)), W) [+ res] -> y or (y, x') with split; with FUSE_BN_INTO_CONV the fused kernel is
     used when the module is in its usual training configuration and one exists for the shape."""
     fused = (FUSE_BN_INTO_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
@@ -235,8 +265,8 @@ def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False):
         return _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split)
     if split:
         z, xs = bn_relu(bn, x, split=True)
-        return _Conv3x3.apply(z, W, stride, dW_slot, res), xs
-    return _Conv3x3.apply(bn_relu(bn, x), W, stride, dW_slot, res)
+        return conv3x3(z, W, stride, dW_slot, res, stats), xs
+    return conv3x3(bn_relu(bn, x), W, stride, dW_slot, res, stats)
 
 
 class _Shortcut(torch.autograd.Function):
@@ -263,7 +293,7 @@ def bn_relu(bn, x, relu=True, split=False):
         z = F.relu(z) if relu else z
         return (z, x) if split else z
     if bn.training or bn.running_mean is None:
-        return _BnRelu.apply(x, bn.weight, bn.bias, bn, relu, split)
+        return _BnRelu.apply(x, bn.weight, bn.bias, bn, relu, split, False, _stats_of(x))
     if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
         z = bn(x)  # gradients through running-statistics normalisation: stock operator
         z = F.relu(z) if relu else z
@@ -389,8 +419,8 @@ class QConv2d(_QuantBase):
         w, slot = self.synthesize()
         if self.mode == "train":
             if bn is not None:
-                return bn_relu_conv(bn, x, w, self.stride, slot, res, split)
-            return _Conv3x3.apply(x, w, self.stride, slot, res)
+                return bn_relu_conv(bn, x, w, self.stride, slot, res, split, stats=self.training)
+            return conv3x3(x, w, self.stride, slot, res, stats=self.training)
         xs = x
         if bn is not None:
             x = bn_relu(bn, x)
@@ -488,7 +518,7 @@ class QResNet(nn.Module):
         an ordinary dense parameter, the arithmetic runs on the same MFMA convolution kernels."""
         c0 = self.conv0
         if c0.kernel_size == (3, 3) and c0.padding == (1, 1) and c0.stride in ((1, 1), (2, 2)) and c0.bias is None:
-            return _Conv3x3.apply(x, c0.weight, c0.stride[0], None, None)
+            return conv3x3(x, c0.weight, c0.stride[0], None, None, stats=self.training)
         return c0(x)
 
     def forward(self, x):

@@ -167,20 +167,33 @@ def conv_out_shape(x_shape, Cout, stride):
     return (N, Cout, (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1)
 
 
-def conv_forward(x, W, stride=1, res=None):
+def conv_forward(x, W, stride=1, res=None, stats=False):
     """y = conv2d(x, W, stride, padding=1) [+ res], W (Cout, Cin, 3, 3)  (adp_qtz_fan.py:574-601;
-    res: the shortcut added after conv2, :676-677)."""
+    res: the shortcut added after conv2, :676-677).
+    stats=True returns (y, st): st = (buffer, descriptor) holds per-workgroup channel statistics of y written
+    by the convolution's epilogue, which bn_relu_forward(y, ..., conv_stats=st) takes in place of its own
+    statistics pass; st is None for shapes without that epilogue."""
     if W.dim() != 4 or W.shape[2] != 3 or W.shape[3] != 3 or x.dim() != 4 or W.shape[1] != x.shape[1]:
         raise ValueError("conv_forward: x %s / W %s: need NCHW input and (Cout, Cin, 3, 3) weights" % (tuple(x.shape), tuple(W.shape)))
     y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride), dtype=torch.float32, device=x.device)
     dims = _conv_dims(x.shape, W.shape[0], stride)
+    if res is not None and tuple(res.shape) != tuple(y.shape):
+        raise ValueError("conv_forward: res %s does not match the output %s" % (tuple(res.shape), tuple(y.shape)))
+    if stats:
+        nbytes = _lib.lib().aq_conv_stats_bytes(*dims) if x.shape[0] > 0 else 0
+        if nbytes > 0:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            desc = _lib.AqConvStats()
+            _lib.check(_lib.lib().aq_conv_fwd_stats(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(y), *dims,
+                                                    buf.data_ptr(), nbytes, C.byref(desc), _lib.stream()))
+            return y, (buf, desc)
     if res is None:
         _lib.check(_lib.lib().aq_conv_fwd(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(y), *dims, _lib.stream()))
     else:
         if tuple(res.shape) != tuple(y.shape):
             raise ValueError("conv_forward: res %s does not match the output %s" % (tuple(res.shape), tuple(y.shape)))
         _lib.check(_lib.lib().aq_conv_fwd_add(_lib.ptr(x, name="x"), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(y), *dims, _lib.stream()))
-    return y
+    return (y, None) if stats else y
 
 
 def conv_forward_codes(x, idx, q, stride=1):
@@ -275,12 +288,13 @@ def _bn_dims(x):
 
 
 def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1,
-                    relu=True, use_running_stats=False, pool=False):
+                    relu=True, use_running_stats=False, pool=False, conv_stats=None):
     """y = [relu](batch_norm(x)) over (N, H, W) of an NCHW tensor (adp_qtz_fan.py:674-675, 690, 726, 730).
     Batch-statistics mode returns (y, save_mean, save_rstd) and updates the running statistics in
     place like nn.BatchNorm2d in training mode; use_running_stats=True normalises with them instead.
     pool=True returns the mean of y over each (image, channel) plane, shape (N, C), instead of y (the
-    network's tail, adp_qtz_fan.py:730-731)."""
+    network's tail, adp_qtz_fan.py:730-731).
+    conv_stats: the second result of conv_forward(..., stats=True) for this very x (batch-statistics mode)."""
     N, Cn, HW = _bn_dims(x)
     y = torch.empty((N, Cn), dtype=torch.float32, device=x.device) if pool else torch.empty_like(x)
     flags = (_lib.BN_RELU if relu else 0) | (_lib.BN_EVAL if use_running_stats else 0)
@@ -289,14 +303,19 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
     if not use_running_stats:
         mean = torch.empty(Cn, dtype=torch.float32, device=x.device)
         rstd = torch.empty(Cn, dtype=torch.float32, device=x.device)
-        nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
-        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        if conv_stats is not None:
+            ws, desc = conv_stats
+            nbytes = ws.numel()
+        else:
+            nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    desc = C.byref(conv_stats[1]) if (conv_stats is not None and not use_running_stats) else None
     fn = _lib.lib().aq_bn_relu_pool_fwd if pool else _lib.lib().aq_bn_relu_fwd
     _lib.check(fn(
         _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
         _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), N, Cn, HW,
         float(eps), float(momentum), flags, _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), ws.data_ptr() if ws is not None else None, nbytes,
-        _lib.stream()))
+        desc, _lib.stream()))
     return y, mean, rstd
 
 

@@ -534,6 +534,61 @@ def test_bnconv_unsupported_shapes_are_reported():
                            torch.zeros(80, 8, 3, 3, device=DEV), 1)
 
 
+# --------------------------------------- convolution that leaves its output's channel statistics behind
+# The epilogue sums per workgroup what the statistics pass sums per slice: other grouping, so the merged
+# mean / variance agree to rounding (a few 1e-7 relative), not to the bit.
+
+@pytest.mark.parametrize("shape", [(3, 16, 1, 32, 128), (16, 16, 1, 32, 128), (16, 32, 2, 32, 128), (32, 32, 1, 16, 128), (32, 64, 2, 16, 128),
+                                   (64, 64, 1, 8, 128), (16, 16, 1, 32, 3), (64, 64, 1, 8, 1), (32, 32, 1, 16, 5), (8, 20, 1, 16, 7)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_epilogue_statistics_feed_batch_norm(shape, with_res):
+    cin, cout, s, H, N = shape
+    rs = np.random.RandomState(sum(shape) + with_res)
+    x = cu(rs.standard_normal((N, cin, H, H)) * 1.3 + 0.2)
+    W = cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+    y_ref = ops.conv_forward(x, W, s)
+    res = cu(rs.standard_normal(tuple(y_ref.shape)) + 0.5) if with_res else None
+    if with_res:
+        y_ref = ops.conv_forward(x, W, s, res)
+    y, st = ops.conv_forward(x, W, s, res, stats=True)
+    assert st is not None, "ResNet-20 shapes have the statistics epilogue"
+    assert torch.equal(y, y_ref)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(cout)), cu(0.2 * rs.standard_normal(cout))
+    for pool in (False, True):
+        rm1, rv1, n1 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        rm2, rv2, n2 = rm1.clone(), rv1.clone(), n1.clone()
+        z1, mean1, rstd1 = ops.bn_relu_forward(y, g, b, rm1, rv1, n1, pool=pool)
+        z2, mean2, rstd2 = ops.bn_relu_forward(y, g, b, rm2, rv2, n2, pool=pool, conv_stats=st)
+        # against float64 statistics of y
+        yd = y.double()
+        m64, v64 = yd.mean(dim=(0, 2, 3)), yd.var(dim=(0, 2, 3), unbiased=False)
+        scale = max(1.0, float(m64.abs().max()))
+        assert (mean2.double() - m64).abs().max().item() <= 2e-6 * scale
+        assert ((rstd2.double() - (v64 + 1e-5).rsqrt()) / (v64 + 1e-5).rsqrt()).abs().max().item() <= 5e-6
+        assert torch.allclose(mean1, mean2, rtol=0, atol=2e-6 * scale) and torch.allclose(rstd1, rstd2, rtol=1e-5, atol=0)
+        assert torch.allclose(rm1, rm2, rtol=0, atol=1e-6 * scale) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-7) and int(n2) == 1
+        assert (z1 - z2).abs().max().item() <= 2e-5 * max(1.0, float(z1.abs().max()))
+    # determinism
+    y3, st3 = ops.conv_forward(x, W, s, res, stats=True)
+    assert torch.equal(st3[0], st[0])
+
+
+def test_conv_epilogue_statistics_unsupported_shapes_and_errors():
+    x = torch.randn(2, 8, 40, 36, device=DEV)
+    W = torch.randn(12, 8, 3, 3, device=DEV)
+    y, st = ops.conv_forward(x, W, 1, stats=True)  # tiles narrower than the output: no epilogue, plain convolution
+    assert st is None and torch.equal(y, ops.conv_forward(x, W, 1))
+    lib = ops._lib.lib()
+    assert lib.aq_conv_stats_bytes(2, 8, 40, 36, 12, 3, 1, 1) == 0
+    assert lib.aq_conv_stats_bytes(128, 16, 32, 32, 16, 3, 1, 1) > 0
+    # a descriptor that does not describe the tensor is refused
+    x2 = torch.randn(4, 16, 32, 32, device=DEV)
+    y2, st2 = ops.conv_forward(x2, torch.randn(16, 16, 3, 3, device=DEV), 1, stats=True)
+    g, b = torch.ones(16, device=DEV), torch.zeros(16, device=DEV)
+    with pytest.raises(RuntimeError, match="do not describe"):
+        ops.bn_relu_forward(y2[:2].contiguous(), g, b, conv_stats=st2)
+
+
 # ------------------------------------------------------------------------------------ loss tail
 
 @pytest.mark.parametrize("shape", [(128, 10), (1, 10), (300, 7), (5, 1), (64, 100)])

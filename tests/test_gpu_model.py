@@ -279,12 +279,15 @@ def test_eval_mode_batchnorm_uses_running_statistics():
 
 
 def test_bn_fused_into_conv_gives_the_same_training_step():
-    """layers.FUSE_BN_INTO_CONV: same operation sequence, so logits, loss and every gradient are bit-equal."""
+    """layers.FUSE_BN_INTO_CONV: same operation sequence, so logits, loss and every gradient are bit-equal
+    (with the statistics pass as the source of the batch statistics on both sides: the fused kernel
+    merges that pass's partials, not the ones a convolution's epilogue leaves behind)."""
     import quantized_cnn_amd.layers as layers
     conf = cfg()
     outs = []
     for fused in (False, True):
         layers.FUSE_BN_INTO_CONV = fused
+        layers.CONV_EMITS_BN_STATS = False
         try:
             torch.manual_seed(0)
             m = fan.ResNet(conf, 3).cuda().train()
@@ -297,6 +300,33 @@ def test_bn_fused_into_conv_gives_the_same_training_step():
             outs.append((logits.detach(), loss.detach(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()]))
         finally:
             layers.FUSE_BN_INTO_CONV = False
+            layers.CONV_EMITS_BN_STATS = True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2] + outs[0][3], outs[1][2] + outs[1][3]):
         assert torch.equal(a, b)
+
+
+def test_conv_epilogue_statistics_give_the_same_training_step():
+    """layers.CONV_EMITS_BN_STATS: the batch statistics come from the producing convolution's epilogue
+    instead of a pass over its output; same values up to summation order."""
+    import quantized_cnn_amd.layers as layers
+    conf = cfg()
+    outs = []
+    for emit in (False, True):
+        layers.CONV_EMITS_BN_STATS = emit
+        try:
+            torch.manual_seed(0)
+            m = fan.ResNet(conf, 3).cuda().train()
+            g = torch.Generator(device="cuda").manual_seed(1)
+            x = torch.randn(16, 3, 32, 32, device="cuda", generator=g)
+            y = torch.randint(0, 10, (16,), device="cuda", generator=g)
+            logits = m(x)
+            loss = torch.nn.functional.cross_entropy(logits, y) + fan.model_loss(conf, 1, m)
+            loss.backward()
+            outs.append((logits.detach(), loss.detach(), [b.clone() for b in m.buffers()]))
+        finally:
+            layers.CONV_EMITS_BN_STATS = True
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-4 * max(1.0, outs[0][0].abs().max().item())
+    assert abs(float(outs[0][1]) - float(outs[1][1])) <= 1e-5 * abs(float(outs[0][1]))
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6)
