@@ -116,6 +116,17 @@ int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L,
 /* dx = d loss / d x  (autograd of adp_qtz_fan.py:574-601 w.r.t. the input) */
 int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd,
                   int Cout, int ksize, int stride, int pad, void *stream);
+/* aq_conv_dgrad whose input x is z = relu(batch_norm(xb)) (`self.convK(F.relu(self.bnK(x)))`,
+ * adp_qtz_fan.py:674-676, 690-691): dz = d loss / d z as aq_conv_dgrad, and the epilogue also reduces what
+ * the batch-norm backward of that z needs, per workgroup and channel, into `sums` ([Cin][desc->P] pairs,
+ * aq_conv_dgrad_bn_bytes bytes): (sum g, sum g * xhat), g = dz where z > 0 else 0, xhat = (xb - mean) * rstd.
+ * xb, gamma, beta, save_mean, save_rstd: as aq_bn_relu_fwd left them.  aq_bn_relu_bwd takes (sums, desc) in
+ * place of its own reduction pass.  aq_conv_dgrad_bn_bytes == 0: no such epilogue for this shape. */
+size_t aq_conv_dgrad_bn_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad);
+int aq_conv_dgrad_bn(const float *dy, const float *W, float *dz, int N, int Cin, int H, int Wd, int Cout,
+                     int ksize, int stride, int pad, const float *xb, const float *gamma, const float *beta,
+                     const float *save_mean, const float *save_rstd, void *sums, size_t sums_bytes,
+                     aq_conv_stats *desc, void *stream);
 /* dW = d loss / d W  (autograd of adp_qtz_fan.py:574-601 w.r.t. conv_w); deterministic two-stage
  * reduction through `workspace` (aq_conv_wgrad_workspace_bytes). */
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd,
@@ -165,11 +176,13 @@ int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float 
 /* Gradient of the above in batch-statistics mode: dy is d loss / d y; dx = d loss / d x [+ res when
  * res != NULL: the gradient arriving over the block's shortcut, `out + x` adp_qtz_fan.py:677, 692],
  * dgamma[C], dbeta[C] (either may be NULL).  x, gamma, beta must be unchanged since the forward call
- * (the ReLU mask is recomputed from them).  dx may alias dy or res. */
+ * (the ReLU mask is recomputed from them).  dx may alias dy or res.
+ * dgrad_sums != NULL: dy was written by aq_conv_dgrad_bn for this x and `workspace` is that call's `sums`
+ * buffer, *dgrad_sums its descriptor; the reduction pass is skipped (AQ_BN_RELU form only). */
 int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
                    const float *save_mean, const float *save_rstd, const float *res, int N, int C, int HW,
                    unsigned flags, float *dx, float *dgamma, float *dbeta, void *workspace,
-                   size_t workspace_bytes, void *stream);
+                   size_t workspace_bytes, const aq_conv_stats *dgrad_sums, void *stream);
 /* The network's tail `out = F.relu(self.bnlast(out)); out = self.ap(out)` (adp_qtz_fan.py:730-731, ap =
  * nn.AvgPool2d(8) on an 8x8 map, i.e. the mean over the plane) in one step: pooled[N, C] = mean over
  * H*W of [relu](batch_norm(x)); the activated tensor is never written.  Other arguments as

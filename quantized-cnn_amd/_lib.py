@@ -23,7 +23,7 @@ EXPORTS = (
     "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
-    "aq_conv_stats_bytes", "aq_conv_fwd_stats",
+    "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
 )
 
 
@@ -81,7 +81,11 @@ def lib():
         L.aq_conv_stats_bytes.restype = sz
         L.aq_conv_fwd_stats.argtypes = [vp, vp, vp, vp] + conv_dims + [vp, sz, C.POINTER(AqConvStats), vp]
         L.aq_conv_fwd_stats.restype = i
-        L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, vp]
+        L.aq_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, C.c_uint, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp]
+        L.aq_conv_dgrad_bn_bytes.argtypes = conv_dims
+        L.aq_conv_dgrad_bn_bytes.restype = sz
+        L.aq_conv_dgrad_bn.argtypes = [vp, vp, vp] + conv_dims + [vp, vp, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp]
+        L.aq_conv_dgrad_bn.restype = i
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_packed_bytes.argtypes = [C.c_longlong, i]

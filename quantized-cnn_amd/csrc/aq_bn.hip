@@ -201,7 +201,19 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
     const int c = blockIdx.y;
     if (threadIdx.x < 64) {
         const int s = threadIdx.x;
-        const float2 p = s < g.S ? a.part[c * g.S + s] : make_float2(0.0f, 0.0f);
+        float2 p = make_float2(0.0f, 0.0f);
+        if (g.P > 0) {  // sums left behind by the dgrad epilogue: P <= 512 per channel, lane l adds l, l + 64, ..
+            float2 q[BN_CONV_PER_LANE];
+#pragma unroll
+            for (int u = 0; u < BN_CONV_PER_LANE; ++u) q[u] = s + 64 * u < g.P ? a.part[c * g.P + s + 64 * u] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int u = 0; u < BN_CONV_PER_LANE; ++u) {
+                p.x += q[u].x;
+                p.y += q[u].y;
+            }
+        } else if (s < g.S) {
+            p = a.part[c * g.S + s];
+        }
         const float s1 = wave_sum(p.x), s2 = wave_sum(p.y);
         if (threadIdx.x == 0) {
             sc[0] = s1;
@@ -345,15 +357,25 @@ int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, f
 
 static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, const float *gamma, const float *beta, const float *save_mean,
                        const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma, float *dbeta,
-                       void *workspace, size_t workspace_bytes, void *stream)
+                       void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream)
 {
     using namespace aq;
     if (int rc = check_dims("aq_bn_relu_bwd", N, C, HW, true)) return rc;
     AQ_REQUIRE((dy || dpool) && x && gamma && beta && save_mean && save_rstd && dx, -EFAULT, "aq_bn_relu_bwd: NULL pointer");
     AQ_REQUIRE((flags & ~AQ_BN_RELU) == 0, -EINVAL, "aq_bn_relu_bwd: unsupported flags 0x%x (batch-statistics mode only)", flags);
-    const BnGeom g = bn_geom(N, C, HW);
-    AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_bwd: workspace of %zu bytes needed, %zu given",
-               (size_t)C * g.S * sizeof(float2), workspace_bytes);
+    BnGeom g = bn_geom(N, C, HW);
+    if (cs) {
+        AQ_REQUIRE(flags & AQ_BN_RELU, -EINVAL, "aq_bn_relu_bwd: the dgrad epilogue reduces for the ReLU form only");
+        AQ_REQUIRE(cs->P >= 1 && cs->P <= 64 * BN_CONV_PER_LANE && (long long)cs->ntiles * cs->tile_px == (long long)N * HW, -EINVAL,
+                   "aq_bn_relu_bwd: dgrad sums (P=%d, %d tiles of %d pixels) do not describe %d x %d values per channel", cs->P, cs->ntiles,
+                   cs->tile_px, N, HW);
+        AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * cs->P * sizeof(float2), -ENOSPC, "aq_bn_relu_bwd: dgrad sums take %zu bytes, %zu given",
+                   (size_t)C * cs->P * sizeof(float2), workspace_bytes);
+        g.P = cs->P;
+    } else {
+        AQ_REQUIRE(workspace && workspace_bytes >= (size_t)C * g.S * sizeof(float2), -ENOSPC, "aq_bn_relu_bwd: workspace of %zu bytes needed, %zu given",
+                   (size_t)C * g.S * sizeof(float2), workspace_bytes);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool relu = flags & AQ_BN_RELU;
     const bool vec = HW % 4 == 0 && aligned16(x) && (!dy || aligned16(dy)) && aligned16(dx) && (!res || aligned16(res));
@@ -361,7 +383,7 @@ static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, cons
     const dim3 g1(g.S, C), g2(g.S2, C);
 #define AQ_BN_BWD(V, R)                                                                                        \
     {                                                                                                          \
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, R>), g1, dim3(BN_T), 0, st, a, g);                         \
+        if (!cs) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, R>), g1, dim3(BN_T), 0, st, a, g);                \
         if (res) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R, true>), g2, dim3(BN_T), 0, st, a, g);           \
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R, false>), g2, dim3(BN_T), 0, st, a, g);              \
     }
@@ -375,11 +397,11 @@ static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, cons
 
 int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean,
                    const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma,
-                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream)
+                   float *dbeta, void *workspace, size_t workspace_bytes, const aq_conv_stats *dgrad_sums, void *stream)
 {
     AQ_REQUIRE(dy, -EFAULT, "aq_bn_relu_bwd: NULL dy");
     return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, res, N, C, HW, flags, dx, dgamma, dbeta, workspace, workspace_bytes,
-                       stream);
+                       dgrad_sums, stream);
 }
 
 int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta, const float *save_mean,
@@ -388,7 +410,7 @@ int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma
 {
     AQ_REQUIRE(dpooled, -EFAULT, "aq_bn_relu_pool_bwd: NULL dpooled");
     return bn_bwd_impl(nullptr, dpooled, x, gamma, beta, save_mean, save_rstd, nullptr, N, C, HW, flags, dx, dgamma, dbeta, workspace,
-                       workspace_bytes, stream);
+                       workspace_bytes, nullptr, stream);
 }
 
 } // extern "C"

@@ -91,6 +91,11 @@ struct ConvArgs {
     // forward, persistent kernel only: per-workgroup (mean, M2) of every output channel over the pixels the
     // workgroup produced, [M][gridDim.x]; the consumer is the batch normalisation that follows (NULL: off)
     float2 *stat_part;
+    // dgrad, persistent kernel only: the output is d loss / d relu(bn(bx)); the epilogue also reduces what the
+    // batch-norm backward needs, per workgroup and channel: (sum g, sum g * xhat) with g = out where
+    // fma(bx, scale, shift) > 0 else 0, xhat = (bx - mean) * rstd, into bwd_part[M][gridDim.x] (NULL: off)
+    const float *bx, *bgamma, *bbeta, *bmean, *brstd;
+    float2 *bwd_part;
     int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
 };
 
@@ -553,6 +558,19 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.0f;
     const bool stats_on = MODE != MODE_DGRAD && a.stat_part != nullptr;
+    const bool bnb_on = MODE == MODE_DGRAD && a.bwd_part != nullptr;
+    float bsc_o[MT][4], bsh_o[MT][4], bmu_o[MT][4];  // scale, shift, mean of this lane's output channels
+    if (bnb_on) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = min(m0 + 16 * m + 4 * kq + r, a.M - 1);
+                const float mu = a.bmean[ch];
+                scale_shift(a.bgamma[ch], a.bbeta[ch], mu, a.brstd[ch], bsc_o[m][r], bsh_o[m][r]);
+                bmu_o[m][r] = mu;
+            }
+    }
 
     AQ_STAMP(2);
     int tcount_ = 0;
@@ -614,6 +632,21 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
         const long long img = (long long)n * a.M * ohw;
         const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + img, (unsigned)(a.M * ohw) * 4u);
         const __amdgpu_buffer_rsrc_t rsd = make_rsrc(a.res ? a.res + img : a.out + img, (unsigned)(a.M * ohw) * 4u);
+        const __amdgpu_buffer_rsrc_t bxs = make_rsrc(bnb_on ? a.bx + img : a.out + img, (unsigned)(a.M * ohw) * 4u);
+        float xb[NT][MT][4];
+        if (bnb_on) {  // issued before the stores below; consumed after them
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = m0 + 16 * m + 4 * kq + r;
+                        xb[nt][m][r] = buf_load(bxs, ch < a.M ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB, 0);
+                    }
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
@@ -634,13 +667,19 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                         ssum[m][r] += v;
                         ssq[m][r] = __builtin_fmaf(v, v, ssq[m][r]);
                     }
+                    if (bnb_on) {  // exact tilings only; channels beyond M hold zeros
+                        const float xv = xb[nt][m][r];
+                        const float gq = __builtin_fmaf(xv, bsc_o[m][r], bsh_o[m][r]) > 0.0f ? v : 0.0f;
+                        ssum[m][r] += gq;
+                        ssq[m][r] = __builtin_fmaf(gq, xv - bmu_o[m][r], ssq[m][r]);
+                    }
                 }
         }
         __syncthreads();  // every wavefront is done with this tile's LDS image
         if (tcount_ == 0) AQ_STAMP(5);
         ++tcount_;
     }
-    if (stats_on) {
+    if (stats_on || bnb_on) {
         // lanes of a 16-lane row share their channels: row sums by DPP, the four wavefronts through LDS
         // (the weight panel is no longer needed), then one thread per channel in fixed order
         float *red = As;  // [4 wavefronts][16*MT channels][2]
@@ -663,9 +702,13 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                 s1 += red[(w * 16 * MT + tid) * 2];
                 s2 += red[(w * 16 * MT + tid) * 2 + 1];
             }
-            const float cnt = (float)(tcount_ * a.TH * a.TW);
-            const float mean = s1 / cnt;
-            a.stat_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(mean, fmaxf(__builtin_fmaf(-s1, mean, s2), 0.0f));
+            if (bnb_on) {
+                a.bwd_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(s1, s2 * a.brstd[m0 + tid]);
+            } else {
+                const float cnt = (float)(tcount_ * a.TH * a.TW);
+                const float mean = s1 / cnt;
+                a.stat_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(mean, fmaxf(__builtin_fmaf(-s1, mean, s2), 0.0f));
+            }
         }
     }
     AQ_STAMP(6);
@@ -1165,7 +1208,7 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         const bool stats_ok = have && a.TW == a.OW && a.OH % a.TH == 0 && pgrid.x <= (unsigned)CONV_STATS_MAX_PARTS;
         if (plan && stats_ok) *plan = ConvStatsPlan{(int)pgrid.x, (int)gx, a.TH * a.TW};
         if (dry) return have ? 1 : 0;
-        AQ_REQUIRE(!a.stat_part || stats_ok, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
+        AQ_REQUIRE(!(a.stat_part || a.bwd_part) || stats_ok, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
 #define AQ_P(MM, NN, CC, JJ)                                                                                                      \
     {                                                                                                                             \
         auto kern = conv_gemm_persist_kernel<MM, NN, CC, JJ, MODE>;                                                               \
@@ -1195,7 +1238,7 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
     }
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
-    AQ_REQUIRE(!a.stat_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
+    AQ_REQUIRE(!a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
     dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
     if (MT == 4 && NT == 2) AQ_GEMM(4, 2);
@@ -1291,6 +1334,15 @@ int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L,
     return aq::conv_fwd_common(x, nullptr, idx, q, L, nullptr, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd_codes");
 }
 
+static void conv_dgrad_args(aq::ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride)
+{
+    a.N = N; a.Cin = Cin; a.Cout = Cout;
+    a.M = Cin; a.KC = Cout; a.K = Cout * 9;
+    a.OH = H; a.OW = Wd;
+    a.IH = (H + 2 - 3) / stride + 1; a.IW = (Wd + 2 - 3) / stride + 1;
+    a.rs = 1; a.dil = stride;
+}
+
 int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
 {
     using namespace aq;
@@ -1299,12 +1351,43 @@ int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, in
     AQ_REQUIRE(dy && W && dx, -EFAULT, "aq_conv_dgrad: NULL pointer");
     ConvArgs a = {};
     a.in = dy; a.W = W; a.out = dx;
-    a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cin; a.KC = Cout; a.K = Cout * 9;
-    a.OH = H; a.OW = Wd;
-    a.IH = (H + 2 - 3) / stride + 1; a.IW = (Wd + 2 - 3) / stride + 1;
-    a.rs = 1; a.dil = stride;
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
     return launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), "aq_conv_dgrad");
+}
+
+size_t aq_conv_dgrad_bn_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
+{
+    using namespace aq;
+    if (check_conv("aq_conv_dgrad_bn_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
+    ConvArgs a = {};
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    ConvStatsPlan plan;
+    launch_gemm<MODE_DGRAD>(a, N, nullptr, "aq_conv_dgrad_bn_bytes", true, &plan);
+    return (size_t)plan.P * Cin * sizeof(float2);
+}
+
+int aq_conv_dgrad_bn(const float *dy, const float *W, float *dz, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
+                     const float *x, const float *gamma, const float *beta, const float *save_mean, const float *save_rstd, void *sums,
+                     size_t sums_bytes, aq_conv_stats *desc, void *stream)
+{
+    using namespace aq;
+    AQ_REQUIRE(desc, -EFAULT, "aq_conv_dgrad_bn: NULL desc");
+    *desc = aq_conv_stats{0, 0, 0};
+    if (int rc = check_conv("aq_conv_dgrad_bn", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(N >= 1, -EINVAL, "aq_conv_dgrad_bn: empty batch");
+    AQ_REQUIRE(dy && W && dz && x && gamma && beta && save_mean && save_rstd, -EFAULT, "aq_conv_dgrad_bn: NULL pointer");
+    const size_t need = aq_conv_dgrad_bn_bytes(N, Cin, H, Wd, Cout, ksize, stride, pad);
+    AQ_REQUIRE(need > 0, -ENOTSUP, "aq_conv_dgrad_bn: no reduction epilogue for this shape (aq_conv_dgrad_bn_bytes is 0): use aq_conv_dgrad and aq_bn_relu_bwd");
+    AQ_REQUIRE(sums && sums_bytes >= need, -ENOSPC, "aq_conv_dgrad_bn: buffer of %zu bytes needed, %zu given", need, sums_bytes);
+    ConvArgs a = {};
+    a.in = dy; a.W = W; a.out = dz;
+    a.bx = x; a.bgamma = gamma; a.bbeta = beta; a.bmean = save_mean; a.brstd = save_rstd;
+    a.bwd_part = static_cast<float2 *>(sums);
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    ConvStatsPlan plan;
+    if (int rc = launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), "aq_conv_dgrad_bn", false, &plan)) return rc;
+    *desc = aq_conv_stats{plan.P, plan.ntiles, plan.tile_px};
+    return 0;
 }
 
 // LDS bank conflicts of the wgrad operand reads: the 16 lanes jn of a wavefront read 16 consecutive

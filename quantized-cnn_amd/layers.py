@@ -132,21 +132,24 @@ class _Conv3x3(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
-        dW = None
-        if ctx.needs_input_grad[1]:
-            if _wgrad_deferred is not None and ctx.dW_slot is not None:
-                # the gradient lands in the slot at the batched reduction; nothing is handed to autograd
-                # (it would clone the slot into the leaf's .grad)
-                if _wgrad_stream is not None:
-                    _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
-                    with torch.cuda.stream(_wgrad_stream):
-                        ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
-                else:
-                    ws, nslab = ops.conv_wgrad_partial(x, dy, ctx.stride)
-                _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
-            else:
-                dW = ops.conv_wgrad(x, dy, ctx.stride, out=ctx.dW_slot)
+        dW = _weight_grad(x, dy, ctx.stride, ctx.dW_slot) if ctx.needs_input_grad[1] else None
         return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None), None
+
+
+def _weight_grad(x, dy, stride, dW_slot):
+    """dW of a 3x3 convolution for autograd, or None when it is left in dW_slot by the batched reduction at
+    the end of the backward pass (nothing is handed to autograd then: it would clone the slot into the
+    leaf's .grad)."""
+    if _wgrad_deferred is not None and dW_slot is not None:
+        if _wgrad_stream is not None:
+            _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
+            with torch.cuda.stream(_wgrad_stream):
+                ws, nslab = ops.conv_wgrad_partial(x, dy, stride)
+        else:
+            ws, nslab = ops.conv_wgrad_partial(x, dy, stride)
+        _wgrad_deferred.append((ws, dW_slot, nslab, x, dy))
+        return None
+    return ops.conv_wgrad(x, dy, stride, out=dW_slot)
 
 
 # The convolution's epilogue can leave the channel statistics of its output behind, so that the batch
@@ -249,11 +252,48 @@ class _BnReluConv(torch.autograd.Function):
         return dx, dg, db, None, dW, None, None, (dy if ctx.needs_input_grad[7] else None), None
 
 
+class _BnReluThenConv(torch.autograd.Function):
+    """y = conv3x3(relu(batch_norm(x)), W) [+ res] in batch-statistics mode as ONE autograd node over two
+    forward kernels (the activated tensor z is kept for the weight gradient), so that the backward pass
+    can couple its kernels: the input-gradient convolution reduces, in its epilogue, the two per-channel
+    sums the batch-norm backward needs, and that backward is left with its streaming kernel only.
+    conv_stats: statistics of x left behind by the convolution that produced it; holder: dict that receives
+    the statistics of y under "stats" (None: not wanted); split=True also hands x through (second output)
+    so that a shortcut's gradient is added inside the batch-norm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, W, stride, dW_slot, res, split, conv_stats, holder):
+        x = x.contiguous()
+        z, mean, rstd = ops.bn_relu_forward(x, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum,
+                                            relu=True, conv_stats=conv_stats)
+        res = res.contiguous() if res is not None else None
+        if holder is None:
+            y = ops.conv_forward(z, W, stride, res)
+        else:
+            y, holder["stats"] = ops.conv_forward(z, W, stride, res, stats=True)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, z, W)
+        ctx.stride, ctx.dW_slot = stride, dW_slot
+        return (y, x.view_as(x)) if split else y
+
+    @staticmethod
+    def backward(ctx, dy, dalias=None):
+        x, gamma, beta, mean, rstd, z, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW = _weight_grad(z, dy, ctx.stride, ctx.dW_slot) if ctx.needs_input_grad[4] else None
+        dz, sums = ops.conv_dgrad(dy, W, z.shape, ctx.stride, bn=(x, gamma, beta, mean, rstd))
+        dx, dg, db = ops.bn_relu_backward(dz, x, gamma, beta, mean, rstd, res=dalias.contiguous() if dalias is not None else None,
+                                          dgrad_sums=sums)
+        return dx, dg, db, None, dW, None, None, (dy if ctx.needs_input_grad[7] else None), None, None, None
+
+
 # The convolution can normalise its input while staging it (no activated tensor in memory).  Measured on
 # MI355X at batch 128 this only breaks even: every wavefront of the convolution has to merge the channel
 # statistics it needs (17.0 against 15.8 + 4.9 us at 16 channels, 22.1 against 14.0 + 4.9 us at 64), so the
 # separate BatchNorm+ReLU kernel stays the default.
 FUSE_BN_INTO_CONV = False
+# relu(bn(x)) and the convolution consuming it as one autograd node whose backward kernels are coupled (see
+# _BnReluThenConv); False: two independent nodes
+COUPLE_BN_BACKWARD = True
 
 
 def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
@@ -263,6 +303,15 @@ def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
              and (bn.training or bn.running_mean is None) and ops.bnconv_supported(x.shape, W.shape[0], stride))
     if fused:
         return _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split)
+    usual = (COUPLE_BN_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
+             and (bn.training or bn.running_mean is None) and torch.is_grad_enabled())
+    if usual:
+        holder = {} if (stats and CONV_EMITS_BN_STATS) else None
+        out = _BnReluThenConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split, _stats_of(x), holder)
+        y = out[0] if split else out
+        if holder is not None and holder.get("stats") is not None:
+            setattr(y, _STATS_ATTR, (holder["stats"], y._version))
+        return out
     if split:
         z, xs = bn_relu(bn, x, split=True)
         return conv3x3(z, W, stride, dW_slot, res, stats), xs

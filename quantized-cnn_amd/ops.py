@@ -206,10 +206,30 @@ def conv_forward_codes(x, idx, q, stride=1):
     return y
 
 
-def conv_dgrad(dy, W, x_shape, stride=1):
+def conv_dgrad(dy, W, x_shape, stride=1, bn=None):
+    """dx = d loss / d x of conv_forward.  bn = (xb, gamma, beta, save_mean, save_rstd) says that x was
+    relu(batch_norm(xb)): the result is then (dx, sums), where sums = (buffer, descriptor) holds the
+    per-workgroup reductions that bn_relu_backward(dx, xb, ..., dgrad_sums=sums) takes in place of its own
+    reduction pass (None for shapes without that epilogue)."""
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     if tuple(dy.shape) != conv_out_shape(x_shape, W.shape[0], stride):
         raise ValueError("conv_dgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x_shape)))
+    if bn is not None:
+        xb, gamma, beta, mean, rstd = bn
+        if tuple(xb.shape) != tuple(x_shape) or not xb.is_contiguous():
+            raise ValueError("conv_dgrad: bn input %s must be contiguous with the shape of x %s" % (tuple(xb.shape), tuple(x_shape)))
+        dims = _conv_dims(x_shape, W.shape[0], stride)
+        nbytes = _lib.lib().aq_conv_dgrad_bn_bytes(*dims) if x_shape[0] > 0 else 0
+        if nbytes > 0:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+            desc = _lib.AqConvStats()
+            _lib.check(_lib.lib().aq_conv_dgrad_bn(
+                _lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *dims, _lib.ptr(xb, name="xb"), _lib.ptr(gamma, name="weight"),
+                _lib.ptr(beta, name="bias"), _lib.ptr(mean, name="save_mean"), _lib.ptr(rstd, name="save_rstd"), buf.data_ptr(), nbytes,
+                C.byref(desc), _lib.stream()))
+            return dx, (buf, desc)
+        _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *dims, _lib.stream()))
+        return dx, None
     _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *_conv_dims(x_shape, W.shape[0], stride), _lib.stream()))
     return dx
 
@@ -319,7 +339,7 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
     return y, mean, rstd
 
 
-def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True, pool=False):
+def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True, pool=False, dgrad_sums=None):
     """-> (dx [+ res], dgamma, dbeta) of bn_relu_forward in batch-statistics mode.  pool=True: dy is the
     gradient of the pooled output, shape (N, C)."""
     N, Cn, HW = _bn_dims(x)
@@ -331,8 +351,13 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
     dx = torch.empty_like(x)
     dg = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
     db = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
-    nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    if dgrad_sums is not None:
+        if pool or not relu:
+            raise ValueError("bn_relu_backward: dgrad_sums go with the plain ReLU form only")
+        ws, nbytes, desc = dgrad_sums[0], dgrad_sums[0].numel(), C.byref(dgrad_sums[1])
+    else:
+        nbytes, desc = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW), None
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     if pool:
         _lib.check(_lib.lib().aq_bn_relu_pool_bwd(
             _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
@@ -342,7 +367,7 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
     _lib.check(_lib.lib().aq_bn_relu_bwd(
         _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
         _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(res, name="res"), N, Cn, HW,
-        _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), ws.data_ptr(), nbytes, _lib.stream()))
+        _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), ws.data_ptr(), nbytes, desc, _lib.stream()))
     return dx, dg, db
 
 

@@ -589,6 +589,51 @@ def test_conv_epilogue_statistics_unsupported_shapes_and_errors():
         ops.bn_relu_forward(y2[:2].contiguous(), g, b, conv_stats=st2)
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 1, 32, 128), (16, 32, 2, 32, 128), (32, 32, 1, 16, 128), (32, 64, 2, 16, 128), (64, 64, 1, 8, 128),
+                                   (16, 16, 1, 32, 3), (64, 64, 1, 8, 1), (20, 8, 1, 16, 7)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_dgrad_epilogue_sums_feed_batch_norm_backward(shape, with_res):
+    """aq_conv_dgrad_bn + aq_bn_relu_bwd(dgrad_sums) against aq_conv_dgrad + aq_bn_relu_bwd: dz bit-equal, the
+    channel sums grouped differently (per workgroup instead of per slice), so dgamma / dbeta / dx to rounding."""
+    cin, cout, s, H, N = shape
+    rs = np.random.RandomState(sum(shape) + 7 * with_res)
+    xb = cu(rs.standard_normal((N, cin, H, H)) * 1.3 + 0.2)
+    W = cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(cin)), cu(0.2 * rs.standard_normal(cin))
+    z, mean, rstd = ops.bn_relu_forward(xb, g, b)
+    y = ops.conv_forward(z, W, s)
+    dy = cu(rs.standard_normal(tuple(y.shape)))
+    res = cu(rs.standard_normal(tuple(xb.shape))) if with_res else None
+    dz_ref = ops.conv_dgrad(dy, W, xb.shape, s)
+    dx_ref, dg_ref, db_ref = ops.bn_relu_backward(dz_ref, xb, g, b, mean, rstd, res=res)
+    dz, sums = ops.conv_dgrad(dy, W, xb.shape, s, bn=(xb, g, b, mean, rstd))
+    assert sums is not None and torch.equal(dz, dz_ref)
+    dx, dg, db = ops.bn_relu_backward(dz, xb, g, b, mean, rstd, res=res, dgrad_sums=sums)
+    # float64 reference of the two sums
+    live = (z > 0).double()
+    gq = dz_ref.double() * live
+    xh = (xb.double() - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
+    s1, s2 = gq.sum(dim=(0, 2, 3)), (gq * xh).sum(dim=(0, 2, 3))
+    mag1 = gq.abs().sum(dim=(0, 2, 3)).clamp_min(1e-30)
+    mag2 = (gq * xh).abs().sum(dim=(0, 2, 3)).clamp_min(1e-30)
+    assert ((db.double() - s1).abs() / mag1).max().item() <= 2e-6 and ((dg.double() - s2).abs() / mag2).max().item() <= 2e-6
+    assert ((db_ref.double() - s1).abs() / mag1).max().item() <= 2e-6
+    assert (dx - dx_ref).abs().max().item() <= 1e-5 * max(1.0, float(dx_ref.abs().max()))
+    dz2, sums2 = ops.conv_dgrad(dy, W, xb.shape, s, bn=(xb, g, b, mean, rstd))
+    assert torch.equal(sums2[0], sums[0])
+
+
+def test_dgrad_epilogue_unsupported_shape_falls_back():
+    xb = torch.randn(2, 8, 40, 36, device=DEV)
+    W = torch.randn(12, 8, 3, 3, device=DEV)
+    g, b = torch.ones(8, device=DEV), torch.zeros(8, device=DEV)
+    z, mean, rstd = ops.bn_relu_forward(xb, g, b)
+    dy = torch.randn(2, 12, 40, 36, device=DEV)
+    dz, sums = ops.conv_dgrad(dy, W, xb.shape, 1, bn=(xb, g, b, mean, rstd))
+    assert sums is None and torch.equal(dz, ops.conv_dgrad(dy, W, xb.shape, 1))
+    assert ops._lib.lib().aq_conv_dgrad_bn_bytes(2, 8, 40, 36, 12, 3, 1, 1) == 0
+
+
 # ------------------------------------------------------------------------------------ loss tail
 
 @pytest.mark.parametrize("shape", [(128, 10), (1, 10), (300, 7), (5, 1), (64, 100)])

@@ -281,13 +281,15 @@ def test_eval_mode_batchnorm_uses_running_statistics():
 def test_bn_fused_into_conv_gives_the_same_training_step():
     """layers.FUSE_BN_INTO_CONV: same operation sequence, so logits, loss and every gradient are bit-equal
     (with the statistics pass as the source of the batch statistics on both sides: the fused kernel
-    merges that pass's partials, not the ones a convolution's epilogue leaves behind)."""
+    merges that pass's partials, not the ones a convolution's epilogue leaves behind; likewise the
+    backward reductions)."""
     import quantized_cnn_amd.layers as layers
     conf = cfg()
     outs = []
     for fused in (False, True):
         layers.FUSE_BN_INTO_CONV = fused
         layers.CONV_EMITS_BN_STATS = False
+        layers.COUPLE_BN_BACKWARD = False
         try:
             torch.manual_seed(0)
             m = fan.ResNet(conf, 3).cuda().train()
@@ -301,6 +303,7 @@ def test_bn_fused_into_conv_gives_the_same_training_step():
         finally:
             layers.FUSE_BN_INTO_CONV = False
             layers.CONV_EMITS_BN_STATS = True
+            layers.COUPLE_BN_BACKWARD = True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2] + outs[0][3], outs[1][2] + outs[1][3]):
         assert torch.equal(a, b)
@@ -330,3 +333,31 @@ def test_conv_epilogue_statistics_give_the_same_training_step():
     assert abs(float(outs[0][1]) - float(outs[1][1])) <= 1e-5 * abs(float(outs[0][1]))
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6)
+
+
+def test_coupled_bn_backward_gives_the_same_training_step():
+    """layers.COUPLE_BN_BACKWARD: relu(bn(x)) + convolution as one autograd node whose input-gradient
+    convolution reduces for the batch-norm backward; the forward pass is the same kernels (bit-equal), the
+    gradients agree up to the grouping of two per-channel sums."""
+    import quantized_cnn_amd.layers as layers
+    conf = cfg()
+    outs = []
+    for couple in (False, True):
+        layers.COUPLE_BN_BACKWARD = couple
+        try:
+            torch.manual_seed(0)
+            m = fan.ResNet(conf, 3).cuda().train()
+            g = torch.Generator(device="cuda").manual_seed(1)
+            x = torch.randn(16, 3, 32, 32, device="cuda", generator=g)
+            y = torch.randint(0, 10, (16,), device="cuda", generator=g)
+            logits = m(x)
+            loss = torch.nn.functional.cross_entropy(logits, y) + fan.model_loss(conf, 1, m)
+            loss.backward()
+            outs.append((logits.detach(), loss.detach(), [(n, p.grad.clone()) for n, p in m.named_parameters()], [b.clone() for b in m.buffers()]))
+        finally:
+            layers.COUPLE_BN_BACKWARD = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][3], outs[1][3]):
+        assert torch.equal(a, b)
+    for (n, a), (_, b) in zip(outs[0][2], outs[1][2]):
+        assert grad_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4), n
