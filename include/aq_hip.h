@@ -127,6 +127,20 @@ int aq_conv_dgrad_bn(const float *dy, const float *W, float *dz, int N, int Cin,
                      int ksize, int stride, int pad, const float *xb, const float *gamma, const float *beta,
                      const float *save_mean, const float *save_rstd, void *sums, size_t sums_bytes,
                      aq_conv_stats *desc, void *stream);
+/* Both gradients of one convolution (autograd of adp_qtz_fan.py:574-601) from one call: dx as aq_conv_dgrad
+ * (or, with xb != NULL, as aq_conv_dgrad_bn with its sums / desc; xb == NULL: gamma .. desc may be NULL) and
+ * the weight-gradient slabs as aq_conv_wgrad_partial (x = the convolution's input; workspace / nslab as
+ * there, to be finished by aq_conv_wgrad_reduce).  The two computations are independent and each alone
+ * leaves most of the chip idle at these sizes, so where a kernel pair exists for the shape they run as ONE
+ * launch with their workgroups side by side on the same CUs; otherwise as two launches.  Results are those
+ * of the separate entry points, bit for bit.  With xb != NULL and desc->P == 0 on return the shape has no
+ * reduction epilogue: call aq_bn_relu_bwd without dgrad_sums.  aq_conv_bwd_sums_bytes: size of `sums`. */
+size_t aq_conv_bwd_sums_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad);
+int aq_conv_bwd(const float *dy, const float *W, const float *x, float *dx, int N, int Cin, int H, int Wd,
+                int Cout, int ksize, int stride, int pad, const float *xb, const float *gamma,
+                const float *beta, const float *save_mean, const float *save_rstd, void *sums,
+                size_t sums_bytes, aq_conv_stats *desc, void *workspace, size_t workspace_bytes, int *nslab,
+                void *stream);
 /* dW = d loss / d W  (autograd of adp_qtz_fan.py:574-601 w.r.t. conv_w); deterministic two-stage
  * reduction through `workspace` (aq_conv_wgrad_workspace_bytes). */
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd,

@@ -24,6 +24,7 @@ EXPORTS = (
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
+    "aq_conv_bwd_sums_bytes", "aq_conv_bwd",
 )
 
 
@@ -86,6 +87,10 @@ def lib():
         L.aq_conv_dgrad_bn_bytes.restype = sz
         L.aq_conv_dgrad_bn.argtypes = [vp, vp, vp] + conv_dims + [vp, vp, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp]
         L.aq_conv_dgrad_bn.restype = i
+        L.aq_conv_bwd_sums_bytes.argtypes = conv_dims
+        L.aq_conv_bwd_sums_bytes.restype = sz
+        L.aq_conv_bwd.argtypes = [vp, vp, vp, vp] + conv_dims + [vp, vp, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp, sz, C.POINTER(C.c_int), vp]
+        L.aq_conv_bwd.restype = i
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_packed_bytes.argtypes = [C.c_longlong, i]

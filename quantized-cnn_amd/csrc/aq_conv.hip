@@ -330,9 +330,15 @@ __device__ __forceinline__ float row16_sum(float v)
 // band) with stride gridDim.x: the input of the NEXT tile is loaded into registers while the MFMAs
 // of the current tile run, and the main loop touches only LDS, so those loads stay in flight.
 // CH4 = input channels per wavefront, J = plane elements per lane.
+// position of a workgroup in the grid its kernel body was written for (a launch that runs several bodies side by
+// side hands every workgroup the coordinates it would have had in a launch of its own)
+struct BlockCoord {
+    int x, y, z, gx;
+};
+
 template <int MT, int NT, int CH4, int J, int MODE>
-__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift,
-                                                                const unsigned k4n_rcp)
+__device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const int ntiles, const int pitch_mul, const int tw_shift,
+                                                       const unsigned k4n_rcp, const BlockCoord bc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *ktab = reinterpret_cast<int *>(smem);       // [Kpad]
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jn = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.y * 16 * MT;
+    const int m0 = bc.y * 16 * MT;
     AQ_STAMP(0);
 
     for (int k = tid; k < a.Kpad; k += 256) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
     };
 
     // the first tile's loads are issued before the weight panel's, so both are in flight together
-    int tile = blockIdx.x;
+    int tile = bc.x;
     if (tile < ntiles) fetch_tile(tile);
     AQ_STAMP(1);
 
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
             gam[u] = a.bn.gamma[cs[u] >= 0 ? cs[u] : 0];
             bet[u] = a.bn.beta[cs[u] >= 0 ? cs[u] : 0];
         }
-        bn_channel_stats_multi<CH4>(a.bn, a.bng, cs, lane, blockIdx.x == 0 && blockIdx.y == 0, mean, rstd);
+        bn_channel_stats_multi<CH4>(a.bn, a.bng, cs, lane, bc.x == 0 && bc.y == 0, mean, rstd);
         float sc[CH4], sh[CH4];
 #pragma unroll
         for (int u = 0; u < CH4; ++u) scale_shift(gam[u], bet[u], mean[u], rstd[u], sc[u], sh[u]);
@@ -574,11 +580,11 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
 
     AQ_STAMP(2);
     int tcount_ = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile += bc.gx) {
         commit_tile();
         __syncthreads();  // image (and, the first time, tables and weight panel) visible
         if (tcount_ == 0) AQ_STAMP(3);
-        const int next = tile + gridDim.x;
+        const int next = tile + bc.gx;
         if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
 
         floatx4 acc[MT][NT];
@@ -703,15 +709,23 @@ __global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a
                 s2 += red[(w * 16 * MT + tid) * 2 + 1];
             }
             if (bnb_on) {
-                a.bwd_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(s1, s2 * a.brstd[m0 + tid]);
+                a.bwd_part[(m0 + tid) * bc.gx + bc.x] = make_float2(s1, s2 * a.brstd[m0 + tid]);
             } else {
                 const float cnt = (float)(tcount_ * a.TH * a.TW);
                 const float mean = s1 / cnt;
-                a.stat_part[(m0 + tid) * gridDim.x + blockIdx.x] = make_float2(mean, fmaxf(__builtin_fmaf(-s1, mean, s2), 0.0f));
+                a.stat_part[(m0 + tid) * bc.gx + bc.x] = make_float2(mean, fmaxf(__builtin_fmaf(-s1, mean, s2), 0.0f));
             }
         }
     }
     AQ_STAMP(6);
+}
+
+template <int MT, int NT, int CH4, int J, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift,
+                                                                const unsigned k4n_rcp)
+{
+    conv_gemm_persist_body<MT, NT, CH4, J, MODE>(a, ntiles, pitch_mul, tw_shift, k4n_rcp,
+                                                 BlockCoord{(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x});
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -741,7 +755,7 @@ struct WgradArgs {
 // (CH4 input channels per wavefront, J image elements per lane) for one phase before writing it to
 // LDS, so their loads are in flight during a whole compute phase.  CH4 == 0: generic loader.
 template <int MG, int NG, int CH4, int J>
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockCoord bc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int npix = a.TH * a.TW;
@@ -752,13 +766,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     const int jn = lane & 15, kq = lane >> 4;
     AQ_STAMP(0);
 
-    int bx = blockIdx.x;
+    int bx = bc.x;
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
     const int ig = bx / a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int m0 = blockIdx.y * 16 * MG;   // first output channel of this group
-    const int j0 = blockIdx.z * 16 * NG;   // first (ci, tap) column of this group
+    const int m0 = bc.y * 16 * MG;   // first output channel of this group
+    const int j0 = bc.z * 16 * NG;   // first (ci, tap) column of this group
     const int c_lo = j0 / 9;               // first input channel those columns touch
     const int ceff = min(a.Cin - c_lo, a.CW);  // channels staged by this workgroup
 
@@ -1036,7 +1050,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     AQ_STAMP(12);
 
     // ---- sum the 4 compute wavefronts in LDS (fixed order 0+1+2+3), write the workgroup's slab ------
-    float *part = a.part + (long long)blockIdx.x * a.Cout * a.K9;
+    float *part = a.part + (long long)bc.x * a.Cout * a.K9;
     constexpr int TPR = 8;  // tiles per round: 8 tiles * 4 waves * 256 floats = 32 KiB
     float *red = smem;
     for (int base = 0; base < MG * NG; base += TPR) {
@@ -1074,6 +1088,41 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
         }
     }
     AQ_STAMP(13);
+}
+
+template <int MG, int NG, int CH4, int J>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
+{
+    conv_wgrad_body<MG, NG, CH4, J>(a, BlockCoord{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x});
+}
+
+// Both gradients of one convolution in ONE launch.  The input gradient (persistent GEMM, 4 wavefronts per
+// workgroup) and the weight-gradient slabs (8 wavefronts) read the same dy and do not depend on each other;
+// each of them alone leaves most of a CU idle (latency-bound at this problem size), so their workgroups run
+// side by side on the same CUs.  Workgroups have 512 threads; in the
+// input-gradient role the upper four wavefronts leave at once (a barrier counts live wavefronts only).
+struct FusedGrid {
+    int d_gx, d_gy;        // grid of the input-gradient body
+    int w_gx, w_gy, w_gz;  // grid of the weight-gradient body
+};
+template <int MT, int NT, int CH4, int J, int MG, int NG, int WCH4, int WJ>
+__global__ __launch_bounds__(512) void conv_bwd_fused_kernel(const ConvArgs a, const int ntiles, const int pitch_mul, const int tw_shift,
+                                                             const unsigned k4n_rcp, const WgradArgs w, const FusedGrid fg)
+{
+    // Workgroups are handed out in index order, round-robin over the XCDs and their CUs, so a role must own a
+    // contiguous run of about one workgroup per CU to land on every CU: the weight-gradient workgroups (the
+    // longer ones) come first, the input-gradient workgroups fill in beside them.
+    const int n2 = fg.w_gx * fg.w_gy * fg.w_gz, b = blockIdx.x;
+    const int role = b < n2 ? 1 : 0, idx = b < n2 ? b : b - n2;
+    if (role == 0) {
+        if (threadIdx.x >= 256) return;
+        const int by = idx / fg.d_gx;
+        conv_gemm_persist_body<MT, NT, CH4, J, MODE_DGRAD>(a, ntiles, pitch_mul, tw_shift, k4n_rcp, BlockCoord{idx - by * fg.d_gx, by, 0, fg.d_gx});
+    } else {
+        const int bz = idx / (fg.w_gx * fg.w_gy), rem = idx - bz * (fg.w_gx * fg.w_gy);
+        const int by = rem / fg.w_gx;
+        conv_wgrad_body<MG, NG, WCH4, WJ>(w, BlockCoord{rem - by * fg.w_gx, by, bz, fg.w_gx});
+    }
 }
 
 // dW[i] = sum over the workgroup slabs.  A workgroup owns 32 consecutive elements; 8 thread rows
@@ -1147,6 +1196,10 @@ static void pick_tile(int OW, int npix, int &TW, int &TH)
 // w, w + P, .. of ntiles, tile_px pixels each (P == 0: this shape has no statistics epilogue).
 struct ConvStatsPlan {
     int P, ntiles, tile_px;
+    // the persistent launch itself (persist == 0: another kernel runs this shape)
+    int persist, MT, NT, c4, jj, pitch_mul, tw_shift;
+    unsigned grid_x, grid_y, k4n_rcp;
+    size_t lds;
 };
 constexpr int CONV_STATS_MAX_PARTS = 512;  // the consumer keeps ceil(P / 64) partials per lane in registers
 
@@ -1154,7 +1207,7 @@ constexpr int CONV_STATS_MAX_PARTS = 512;  // the consumer keeps ceil(P / 64) pa
 template <int MODE>
 static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false, ConvStatsPlan *plan = nullptr)
 {
-    if (plan) *plan = ConvStatsPlan{0, 0, 0};
+    if (plan) *plan = ConvStatsPlan{};
     // tile choice: NT = 2 (128 pixels) and MT up to 4, shrunk until the grid fills the chip
     const int mtiles = (a.M + 15) / 16;
     int MT = std::min(4, mtiles), NT = 2;
@@ -1206,7 +1259,9 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         const bool have = !((jj == 5 && c4 > 8) || (jj == 9 && c4 > 4));
         // statistics epilogue: every pixel of every tile is an output pixel, and few enough partials
         const bool stats_ok = have && a.TW == a.OW && a.OH % a.TH == 0 && pgrid.x <= (unsigned)CONV_STATS_MAX_PARTS;
-        if (plan && stats_ok) *plan = ConvStatsPlan{(int)pgrid.x, (int)gx, a.TH * a.TW};
+        if (plan && have) {
+            *plan = ConvStatsPlan{stats_ok ? (int)pgrid.x : 0, (int)gx, a.TH * a.TW, 1, MT, NT, c4, jj, pitch_mul, tw_shift, pgrid.x, pgrid.y, k4n_rcp, plds};
+        }
         if (dry) return have ? 1 : 0;
         AQ_REQUIRE(!(a.stat_part || a.bwd_part) || stats_ok, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
 #define AQ_P(MM, NN, CC, JJ)                                                                                                      \
@@ -1678,6 +1733,83 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
 #undef AQ_WG
     *nslab_out = (int)grid.x;
     return check_launch("aq_conv_wgrad");
+}
+
+size_t aq_conv_bwd_sums_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
+{
+    return aq_conv_dgrad_bn_bytes(N, Cin, H, Wd, Cout, ksize, stride, pad);
+}
+
+int aq_conv_bwd(const float *dy, const float *W, const float *x, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
+                const float *xb, const float *gamma, const float *beta, const float *save_mean, const float *save_rstd, void *sums,
+                size_t sums_bytes, aq_conv_stats *desc, void *workspace, size_t workspace_bytes, int *nslab, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_conv("aq_conv_bwd", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(nslab, -EFAULT, "aq_conv_bwd: NULL nslab");
+    *nslab = 0;
+    if (desc) *desc = aq_conv_stats{0, 0, 0};
+    if (N == 0) return 0;
+    AQ_REQUIRE(dy && W && x && dx, -EFAULT, "aq_conv_bwd: NULL pointer");
+    const bool bn = xb != nullptr;
+    AQ_REQUIRE(!bn || (gamma && beta && save_mean && save_rstd && sums && desc), -EFAULT, "aq_conv_bwd: the batch-norm epilogue needs all of its operands");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    // plans of the two halves
+    ConvArgs a = {};
+    a.in = dy; a.W = W; a.out = dx;
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    ConvStatsPlan plan;
+    launch_gemm<MODE_DGRAD>(a, N, nullptr, "aq_conv_bwd", true, &plan);
+    WgradArgs w = {};
+    w.x = x; w.dy = dy; w.part = static_cast<float *>(workspace);
+    w.N = N; w.Cin = Cin; w.H = H; w.Wd = Wd; w.Cout = Cout; w.stride = stride;
+    int MG, NG;
+    dim3 wgrid;
+    size_t wlds, ws;
+    if (int rc = wgrad_plan(w, MG, NG, wgrid, wlds, ws)) return rc;
+    const int variant = wgrad_variant(w, MG, NG);
+    const size_t lds = std::max(plan.lds, wlds);
+    // one launch when a kernel pair is instantiated for the shape and two workgroups fit on a CU side by side
+    int pair = 0;
+    if (plan.persist && (!bn || plan.P > 0) && 2 * lds <= 160 * 1024) {
+        if (plan.MT == 1 && plan.NT == 2 && plan.c4 == 4 && plan.jj == 5 && variant == 1) pair = 1;
+        else if (plan.MT == 2 && plan.NT == 1 && plan.c4 == 8 && plan.jj == 2 && variant == 3) pair = 2;
+        else if (plan.MT == 1 && plan.NT == 1 && plan.c4 == 16 && plan.jj == 2 && variant == 5) pair = 3;
+    }
+    if (!pair) {
+        if (int rc = aq_conv_wgrad_partial(x, dy, N, Cin, H, Wd, Cout, ksize, stride, pad, workspace, workspace_bytes, nslab, stream)) return rc;
+        if (bn && aq_conv_dgrad_bn_bytes(N, Cin, H, Wd, Cout, ksize, stride, pad) > 0)
+            return aq_conv_dgrad_bn(dy, W, dx, N, Cin, H, Wd, Cout, ksize, stride, pad, xb, gamma, beta, save_mean, save_rstd, sums, sums_bytes, desc,
+                                    stream);
+        return aq_conv_dgrad(dy, W, dx, N, Cin, H, Wd, Cout, ksize, stride, pad, stream);  // desc->P stays 0: no sums
+    }
+    AQ_REQUIRE(workspace && workspace_bytes >= ws, -ENOSPC, "aq_conv_bwd: workspace too small: need %zu bytes, got %zu", ws, workspace_bytes);
+    // one input-gradient workgroup per CU (a launch of its own uses two where LDS allows): the weight-gradient
+    // workgroup beside it is the second one
+    const int d_gx = std::min<int>((int)plan.grid_x, std::max(1, 256 / (int)plan.grid_y));
+    if (bn) {
+        const size_t need = (size_t)d_gx * Cin * sizeof(float2);
+        AQ_REQUIRE(sums_bytes >= need, -ENOSPC, "aq_conv_bwd: buffer of %zu bytes needed for the sums, %zu given", need, sums_bytes);
+        a.bx = xb; a.bgamma = gamma; a.bbeta = beta; a.bmean = save_mean; a.brstd = save_rstd;
+        a.bwd_part = static_cast<float2 *>(sums);
+    }
+    const FusedGrid fg{d_gx, (int)plan.grid_y, (int)wgrid.x, (int)wgrid.y, (int)wgrid.z};
+    const long long blocks = (long long)fg.d_gx * fg.d_gy + (long long)fg.w_gx * fg.w_gy * fg.w_gz;
+    AQ_REQUIRE(blocks < (1LL << 31), -E2BIG, "aq_conv_bwd: grid too large");
+#define AQ_FUSED(MT, NT, C4, JJ, MGG, NGG, WC, WJ)                                                                                   \
+    {                                                                                                                                \
+        auto kern = conv_bwd_fused_kernel<MT, NT, C4, JJ, MGG, NGG, WC, WJ>;                                                         \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, plan.ntiles, plan.pitch_mul, plan.tw_shift, plan.k4n_rcp, w, fg); \
+    }
+    if (pair == 1) AQ_FUSED(1, 2, 4, 5, 1, 9, 4, 4)
+    else if (pair == 2) AQ_FUSED(2, 1, 8, 2, 1, 18, 8, 3)
+    else AQ_FUSED(1, 1, 16, 2, 1, 18, 8, 2)
+#undef AQ_FUSED
+    *nslab = (int)wgrid.x;
+    if (bn) *desc = aq_conv_stats{d_gx, plan.ntiles, plan.tile_px};
+    return check_launch("aq_conv_bwd");
 }
 
 } // extern "C"

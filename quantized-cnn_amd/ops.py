@@ -234,6 +234,36 @@ def conv_dgrad(dy, W, x_shape, stride=1, bn=None):
     return dx
 
 
+def conv_backward(dy, W, x, stride=1, bn=None):
+    """Both gradients of y = conv_forward(x, W, stride) from one call (one launch where the library has a
+    kernel pair for the shape): -> (dx, sums, workspace, nslab).  dx / sums as conv_dgrad(dy, W, x.shape,
+    stride, bn) (sums None without bn or without a reduction epilogue for the shape); workspace / nslab as
+    conv_wgrad_partial(x, dy, stride), to be finished by conv_wgrad_reduce."""
+    Cout = W.shape[0]
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride) or W.shape[1] != x.shape[1]:
+        raise ValueError("conv_backward: dy %s / W %s do not match x %s" % (tuple(dy.shape), tuple(W.shape), tuple(x.shape)))
+    dims = _conv_dims(x.shape, Cout, stride)
+    dx = torch.empty_like(x)
+    nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    nslab = C.c_int(0)
+    desc = _lib.AqConvStats()
+    buf, sbytes, extra = None, 0, [None] * 5
+    if bn is not None:
+        xb, gamma, beta, mean, rstd = bn
+        if tuple(xb.shape) != tuple(x.shape) or not xb.is_contiguous():
+            raise ValueError("conv_backward: bn input %s must be contiguous with the shape of x %s" % (tuple(xb.shape), tuple(x.shape)))
+        sbytes = _lib.lib().aq_conv_bwd_sums_bytes(*dims)
+        buf = torch.empty(max(sbytes, 16), dtype=torch.uint8, device=x.device)
+        extra = [_lib.ptr(xb, name="xb"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(mean, name="save_mean"),
+                 _lib.ptr(rstd, name="save_rstd")]
+    _lib.check(_lib.lib().aq_conv_bwd(
+        _lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(x, name="x"), _lib.ptr(dx), *dims, *extra,
+        buf.data_ptr() if buf is not None else None, sbytes, C.byref(desc), ws.data_ptr(), nbytes, C.byref(nslab), _lib.stream()))
+    sums = (buf, desc) if (bn is not None and desc.P > 0) else None
+    return dx, sums, ws, nslab.value
+
+
 def conv_wgrad(x, dy, stride=1, out=None):
     Cout = dy.shape[1]
     if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):

@@ -634,6 +634,40 @@ def test_dgrad_epilogue_unsupported_shape_falls_back():
     assert ops._lib.lib().aq_conv_dgrad_bn_bytes(2, 8, 40, 36, 12, 3, 1, 1) == 0
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 1, 32, 128), (16, 32, 2, 32, 128), (32, 32, 1, 16, 128), (32, 64, 2, 16, 128), (64, 64, 1, 8, 128),
+                                   (16, 16, 1, 32, 3), (64, 64, 1, 8, 1), (32, 32, 1, 16, 5), (20, 8, 1, 16, 7), (8, 12, 1, 40, 2)])
+@pytest.mark.parametrize("with_bn", [False, True])
+def test_conv_backward_one_call_equals_separate_calls(shape, with_bn):
+    """aq_conv_bwd (input gradient and weight-gradient slabs side by side in one launch where a kernel pair
+    exists) gives the bits of aq_conv_dgrad[_bn] and aq_conv_wgrad_partial."""
+    cin, cout, s, H, N = shape
+    rs = np.random.RandomState(sum(shape) + 3 * with_bn)
+    Wd = 36 if H == 40 else H
+    xb = cu(rs.standard_normal((N, cin, H, Wd)) * 1.3 + 0.2)
+    W = cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(cin)), cu(0.2 * rs.standard_normal(cin))
+    z, mean, rstd = ops.bn_relu_forward(xb, g, b)
+    y = ops.conv_forward(z, W, s)
+    dy = cu(rs.standard_normal(tuple(y.shape)))
+    bn = (xb, g, b, mean, rstd) if with_bn else None
+    dW_ref = ops.conv_wgrad(z, dy, s)
+    if with_bn:
+        dz_ref, sums_ref = ops.conv_dgrad(dy, W, z.shape, s, bn=bn)
+    else:
+        dz_ref, sums_ref = ops.conv_dgrad(dy, W, z.shape, s), None
+    for _ in range(2):
+        dz, sums, ws, nslab = ops.conv_backward(dy, W, z, s, bn=bn)
+        dW = torch.empty_like(W)
+        ops.conv_wgrad_reduce([(ws, dW, nslab)])
+        assert torch.equal(dz, dz_ref) and torch.equal(dW, dW_ref)
+        assert (sums is None) == (sums_ref is None)
+        if sums is not None:  # the sums may be split over another number of workgroups: compare what they merge to
+            got = ops.bn_relu_backward(dz, xb, g, b, mean, rstd, dgrad_sums=sums)
+            want = ops.bn_relu_backward(dz_ref, xb, g, b, mean, rstd, dgrad_sums=sums_ref)
+            for u, v in zip(got, want):
+                assert (u - v).abs().max().item() <= 1e-5 * max(1.0, float(v.abs().max()))
+
+
 # ------------------------------------------------------------------------------------ loss tail
 
 @pytest.mark.parametrize("shape", [(128, 10), (1, 10), (300, 7), (5, 1), (64, 100)])
