@@ -586,6 +586,29 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         if (tcount_ == 0) AQ_STAMP(3);
         const int next = tile + bc.gx;
         if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
+        // the epilogue's second operand (the shortcut added to the output, or the batch-norm input whose
+        // backward sums are reduced) is requested now as well, not after the MFMAs
+        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
+        const int oy0 = ty * a.TH;
+        const int ohw = a.OH * a.OW;
+        const long long img = (long long)n * a.M * ohw;
+        const bool eop = bnb_on || (MODE != MODE_DGRAD && a.res != nullptr);
+        float ev[NT][MT][4];
+        if (eop) {
+            const __amdgpu_buffer_rsrc_t esrc = make_rsrc((bnb_on ? a.bx : a.res) + img, (unsigned)(a.M * ohw) * 4u);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+                const bool pok = pyx[nt] >= 0 && oy < a.OH;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = m0 + 16 * m + 4 * kq + r;
+                        ev[nt][m][r] = buf_load(esrc, (pok && ch < a.M) ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB, 0);
+                    }
+            }
+        }
 
         floatx4 acc[MT][NT];
 #pragma unroll
@@ -632,27 +655,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             __builtin_amdgcn_sched_barrier(0);
         }
         if (tcount_ == 0) AQ_STAMP(4);
-        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
-        const int oy0 = ty * a.TH;
-        const int ohw = a.OH * a.OW;
-        const long long img = (long long)n * a.M * ohw;
         const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + img, (unsigned)(a.M * ohw) * 4u);
-        const __amdgpu_buffer_rsrc_t rsd = make_rsrc(a.res ? a.res + img : a.out + img, (unsigned)(a.M * ohw) * 4u);
-        const __amdgpu_buffer_rsrc_t bxs = make_rsrc(bnb_on ? a.bx + img : a.out + img, (unsigned)(a.M * ohw) * 4u);
-        float xb[NT][MT][4];
-        if (bnb_on) {  // issued before the stores below; consumed after them
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ch = m0 + 16 * m + 4 * kq + r;
-                        xb[nt][m][r] = buf_load(bxs, ch < a.M ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB, 0);
-                    }
-            }
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
@@ -667,14 +670,14 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
                     const int ch = m0 + 16 * m + 4 * kq + r;
                     const unsigned o = (pok && ch < a.M) ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB;
                     float v = acc[m][nt][r];
-                    if (a.res) v += buf_load(rsd, o, 0);
+                    if (MODE != MODE_DGRAD && a.res) v += ev[nt][m][r];
                     buf_store(v, dst, o, 0);
                     if (stats_on) {  // the host enables this for exact tilings only: every pixel is an output
                         ssum[m][r] += v;
                         ssq[m][r] = __builtin_fmaf(v, v, ssq[m][r]);
                     }
                     if (bnb_on) {  // exact tilings only; channels beyond M hold zeros
-                        const float xv = xb[nt][m][r];
+                        const float xv = ev[nt][m][r];
                         const float gq = __builtin_fmaf(xv, bsc_o[m][r], bsh_o[m][r]) > 0.0f ? v : 0.0f;
                         ssum[m][r] += gq;
                         ssq[m][r] = __builtin_fmaf(gq, xv - bmu_o[m][r], ssq[m][r]);

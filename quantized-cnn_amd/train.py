@@ -199,8 +199,8 @@ class FusedTrainStep:
         graph B : regulariser gradient of the dense "weight" tensors (one multi-tensor launch); ONE
                   synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq); 3x Adam
 
-    Both graphs are captured once per (input shape, beta, learning rates) and replayed; with
-    use_graph=False the same two phases run eagerly.
+    The graphs are captured once per (input shape, beta, learning rates) and replayed (a single graph
+    holding both phases when there is no exchange); with use_graph=False the same two phases run eagerly.
     """
 
     def __init__(self, model, config, module, dp=None, use_graph=True, fuse_adam=True, overlap_wgrad=False):
@@ -328,15 +328,16 @@ class FusedTrainStep:
             self._comm()
             self._phase_b()
             return self.loss
-        key = (tuple(x.shape), float(self.module.beta), tuple(g["lr"] for o in self.opts for g in o.param_groups))
+        key = (tuple(x.shape), float(self.module.beta), tuple(g["lr"] for o in self.opts for g in o.param_groups), self._exchange)
         if self._graphs is None or key != self._key:
             self._capture(x, y)
             self._key = key
         self._sx.copy_(x)
         self._sy.copy_(y)
         self._graphs[0].replay()
-        self._comm()
-        self._graphs[1].replay()
+        if self._graphs[1] is not None:
+            self._comm()
+            self._graphs[1].replay()
         return self.loss
 
     def _ensure_adam_state(self):
@@ -373,10 +374,16 @@ class FusedTrainStep:
             for b, v in zip(bufs, saved):
                 b.copy_(v)
             torch.cuda.synchronize()
-            with torch.cuda.graph(ga, stream=s):
-                self._phase_a(self._sx, self._sy)
-            with torch.cuda.graph(gb, stream=s, pool=ga.pool()):
-                self._phase_b()
+            if self._exchange:
+                with torch.cuda.graph(ga, stream=s):
+                    self._phase_a(self._sx, self._sy)
+                with torch.cuda.graph(gb, stream=s, pool=ga.pool()):
+                    self._phase_b()
+            else:  # nothing happens between the phases: one graph, one replay per step
+                gb = None
+                with torch.cuda.graph(ga, stream=s):
+                    self._phase_a(self._sx, self._sy)
+                    self._phase_b()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graphs = (ga, gb)
