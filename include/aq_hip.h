@@ -267,6 +267,21 @@ int aq_augment_batch(const uint8_t *data, long long n_images, const int *index, 
  * pointers / element counts; out: device [n]. */
 int aq_absmax(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
 
+/* torch.optim.Adam's update (defaults: no weight decay, no amsgrad) of many small tensors in one launch per
+ * 48 items: the reference's optimizer_q (q_level vectors) and optimizer (conv0, BatchNorm, linear bias)
+ * steps, adp_qtz_fan.py:223-242, 296-304.  Per item: *step += 1 (one-element fp32 tensor, one per item, as
+ * Adam keeps it with capturable=True), m/v = exp_avg / exp_avg_sq, p updated in place.  reg != 0: g += reg*p
+ * first, written back to g (the regulariser's gradient 2*l2_reg*w of the dense "weight" tensors, model_loss
+ * adp_qtz_fan.py:737-754).  items: HOST array. */
+typedef struct aq_adam_item {
+    float *p, *g, *m, *v, *step;
+    int64_t n;
+    float reg;
+    int32_t reserved;
+} aq_adam_item;
+int aq_adam_step(const aq_adam_item *items, int nitems, double lr, double beta1, double beta2, double eps,
+                 void *stream);
+
 /* Tail of the step, `loss = criterion(logits, y) + model_loss(config, beta, model)` (adp_qtz_fan.py:288-289,
  * criterion = nn.CrossEntropyLoss(), :202; model_loss :737-754):
  * aq_sumsq: out[i] = sum of squares of tensor i (HOST arrays of n device pointers / sizes), one launch

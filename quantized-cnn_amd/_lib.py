@@ -24,7 +24,7 @@ EXPORTS = (
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
-    "aq_conv_bwd_sums_bytes", "aq_conv_bwd",
+    "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
 )
 
 
@@ -39,6 +39,11 @@ class AqSeg(C.Structure):
 
 class AqConvStats(C.Structure):
     _fields_ = [("P", C.c_int32), ("ntiles", C.c_int32), ("tile_px", C.c_int32)]
+
+
+class AqAdamItem(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p),
+                ("n", C.c_int64), ("reg", C.c_float), ("reserved", C.c_int32)]
 
 
 class AqWgradJob(C.Structure):
@@ -91,6 +96,8 @@ def lib():
         L.aq_conv_bwd_sums_bytes.restype = sz
         L.aq_conv_bwd.argtypes = [vp, vp, vp, vp] + conv_dims + [vp, vp, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp, sz, C.POINTER(C.c_int), vp]
         L.aq_conv_bwd.restype = i
+        L.aq_adam_step.argtypes = [C.POINTER(AqAdamItem), i, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        L.aq_adam_step.restype = i
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_packed_bytes.argtypes = [C.c_longlong, i]

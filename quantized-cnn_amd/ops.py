@@ -557,3 +557,28 @@ def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=Tr
                                      _lib.ptr(sumsq_a, name="sumsq_a"), na, _lib.ptr(sumsq_b, name="sumsq_b"), nb, float(l2_reg),
                                      _lib.ptr(d), _lib.ptr(vals), _lib.stream()))
     return vals, d
+
+
+# ------------------------------------------------------------------------------------------ Adam
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, betas=(0.9, 0.999), eps=1e-8, regs=None):
+    """torch.optim.Adam's update (no weight decay / amsgrad) of a list of tensors in one launch per 48 tensors
+    (adp_qtz_fan.py:296-304: optimizer_q.step(), optimizer.step()).  steps: one-element fp32 tensors, one per
+    parameter, advanced by 1.  regs[i] != 0: grads[i] += regs[i] * params[i] first (in place)."""
+    n = len(params)
+    if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == len(steps) == n) or (regs is not None and len(regs) != n):
+        raise ValueError("adam_step: lists of different lengths")
+    if n == 0:
+        return
+    arr = (_lib.AqAdamItem * n)()
+    for i in range(n):
+        p = params[i]
+        for t, name in ((grads[i], "grad"), (exp_avgs[i], "exp_avg"), (exp_avg_sqs[i], "exp_avg_sq")):
+            if t.numel() != p.numel():
+                raise ValueError("adam_step: %s of tensor %d has %d elements, the parameter %d" % (name, i, t.numel(), p.numel()))
+        arr[i].p, arr[i].g = _lib.ptr(p, name="param"), _lib.ptr(grads[i], name="grad")
+        arr[i].m, arr[i].v = _lib.ptr(exp_avgs[i], name="exp_avg"), _lib.ptr(exp_avg_sqs[i], name="exp_avg_sq")
+        arr[i].step = _lib.ptr(steps[i], name="step")
+        arr[i].n = p.numel()
+        arr[i].reg = float(regs[i]) if regs is not None else 0.0
+    _lib.check(_lib.lib().aq_adam_step(arr, n, float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream()))

@@ -196,8 +196,9 @@ class FusedTrainStep:
                   with the synthesised W as leaves -> d loss/d W of every quantized layer lands in one
                   flat buffer; for the exchange the dense gradients are gathered behind them
         comm    : one all-reduce of that buffer (only when world_size > 1; never captured)
-        graph B : regulariser gradient of the dense "weight" tensors (one multi-tensor launch); ONE
-                  synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq); 3x Adam
+        graph B : ONE synthesis-gradient launch (dW + 2*l2_reg*W -> dp_c, dq) with Adam for p_c inside;
+                  Adam of the two small groups, one launch each, with the regulariser gradient of the
+                  dense "weight" tensors folded in
 
     The graphs are captured once per (input shape, beta, learning rates) and replayed (a single graph
     holding both phases when there is no exchange); with use_graph=False the same two phases run eagerly.
@@ -236,6 +237,10 @@ class FusedTrainStep:
         self.nW = nW
         g0 = self.opts[0].param_groups[0]
         self.fuse_adam = bool(fuse_adam) and len(self.ps) <= 24 and not (g0["amsgrad"] or g0["maximize"] or g0["weight_decay"])
+        # the two small groups (q_level vectors; conv0, BatchNorm, linear bias): one launch each instead of the
+        # stock optimizer's multi-tensor kernels, with the regulariser's gradient folded in
+        self.small_adam = self.fuse_adam and all(not (g["amsgrad"] or g["maximize"] or g["weight_decay"])
+                                                 for o in self.opts[1:] for g in o.param_groups)
         self.dp_out = None if self.fuse_adam else [torch.zeros_like(p) for p in self.ps]
         self.dq_out = [torch.zeros_like(q) if q.requires_grad else None for q in self.qs]
         self.dss = torch.full((len(self.ps),), float(config.l2_reg), dtype=torch.float32, device=dev)
@@ -296,7 +301,7 @@ class FusedTrainStep:
                 views.append(self.g_flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             torch._foreach_copy_([p.grad for p in self.dense], views)
-        if self.dense_reg:
+        if self.dense_reg and not self.small_adam:
             torch._foreach_add_([p.grad for p in self.dense_reg], [p.detach() for p in self.dense_reg], alpha=2.0 * float(self.config.l2_reg))
         ps, qs = [p.detach() for p in self.ps], [q.detach() for q in self.qs]
         if self.fuse_adam:
@@ -314,6 +319,16 @@ class FusedTrainStep:
         for q, g in zip(self.qs, self.dq_out):
             if g is not None:
                 q.grad = g
+        if self.small_adam:
+            reg_ids, coef = {id(p) for p in self.dense_reg}, 2.0 * float(self.config.l2_reg)
+            for o in self.opts[1:]:
+                for grp in o.param_groups:
+                    prm = [p for p in grp["params"] if p.grad is not None]
+                    st = [o.state[p] for p in prm]
+                    ops.adam_step([p.detach() for p in prm], [p.grad for p in prm], [t["exp_avg"] for t in st], [t["exp_avg_sq"] for t in st],
+                                  [t["step"] for t in st], lr=grp["lr"], betas=grp["betas"], eps=grp["eps"],
+                                  regs=[coef if id(p) in reg_ids else 0.0 for p in prm])
+            return
         for o in (self.opts[1:] if self.fuse_adam else self.opts):
             o.step()
 
@@ -332,13 +347,21 @@ class FusedTrainStep:
         if self._graphs is None or key != self._key:
             self._capture(x, y)
             self._key = key
-        self._sx.copy_(x)
-        self._sy.copy_(y)
+        if x is not self._sx:
+            self._sx.copy_(x)
+        if y is not self._sy:
+            self._sy.copy_(y)
         self._graphs[0].replay()
         if self._graphs[1] is not None:
             self._comm()
             self._graphs[1].replay()
         return self.loss
+
+    def static_inputs(self):
+        """(x, y) buffers the captured graphs read, or None before the first graph step.  A producer that
+        writes a batch straight into them (and passes these very tensors to the step) saves the two copies
+        per step."""
+        return (self._sx, self._sy) if (self.use_graph and self._graphs is not None) else None
 
     def _ensure_adam_state(self):
         """Adam creates its state lazily in step(); create it up front (same tensors, same state_dict

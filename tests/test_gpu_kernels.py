@@ -701,3 +701,51 @@ def test_ce_loss_and_sumsq_vs_oracle_and_torch(shape):
     bad = torch.from_numpy(y).cuda().clone()
     bad[0] = Cn
     assert np.isnan(ops.ce_loss(cu(x), bad)[0][0].item())
+
+
+# ------------------------------------------------------------------------------ small-tensor Adam
+
+def test_adam_step_vs_oracle_and_torch():
+    """aq_adam_step on a mixed bag of small tensors (more than one launch's worth): against the C oracle's
+    Adam and against torch.optim.Adam(fused=True) fed the same gradients; reg adds reg*p to the gradient."""
+    rs = np.random.RandomState(5)
+    sizes = [32] * 20 + [432, 10, 1, 7] + [16, 16, 32, 32, 64, 64] * 6 + [36864]
+    ps = [cu(rs.standard_normal(n)) for n in sizes]
+    regs = [2e-4 if i % 3 == 0 else 0.0 for i in range(len(sizes))]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3, fused=True)
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    steps = [torch.zeros((), device=DEV) for _ in ps]
+    op, om, ov = [p.cpu().numpy().copy() for p in ps], [np.zeros(n, np.float32) for n in sizes], [np.zeros(n, np.float32) for n in sizes]
+    for t in range(1, 4):
+        gs = [cu(rs.standard_normal(n) * 0.1) for n in sizes]
+        for r, g, reg in zip(ref, gs, regs):
+            r.grad = g + reg * r.detach()
+        opt.step()
+        for i, g in enumerate(gs):
+            gi = (g.cpu().numpy() + np.float32(regs[i]) * op[i]).astype(np.float32)
+            O.adam_step(op[i], gi, om[i], ov[i], t, 1e-3)
+        g_in = [g.clone() for g in gs]
+        ops.adam_step(ps, g_in, m, v, steps, 1e-3, regs=regs)
+        for i in range(len(sizes)):
+            if regs[i]:
+                assert (g_in[i] - ref[i].grad).abs().max().item() <= 1e-7 * max(1.0, float(ref[i].grad.abs().max()))
+            else:
+                assert torch.equal(g_in[i], gs[i])
+            assert np.abs(ps[i].cpu().numpy() - op[i]).max() <= 2e-6, (t, i)
+            assert (ps[i] - ref[i].detach()).abs().max().item() <= 2e-6, (t, i)
+            assert float(steps[i]) == t
+    st = opt.state[ref[-1]]
+    assert torch.allclose(m[-1], st["exp_avg"], rtol=1e-4, atol=1e-8) and torch.allclose(v[-1], st["exp_avg_sq"], rtol=1e-4, atol=1e-10)
+
+
+def test_adam_step_argument_errors():
+    p = torch.zeros(4, device=DEV)
+    st = torch.zeros((), device=DEV)
+    with pytest.raises(RuntimeError, match="share a step counter"):
+        ops.adam_step([p, p.clone()], [p.clone(), p.clone()], [p.clone(), p.clone()], [p.clone(), p.clone()], [st, st], 1e-3)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.adam_step([p], [p.clone()], [p.clone()], [p.clone()], [st], 1e-3, betas=(1.0, 0.9))
+    with pytest.raises(ValueError, match="elements"):
+        ops.adam_step([p], [torch.zeros(3, device=DEV)], [p.clone()], [p.clone()], [st], 1e-3)
