@@ -1567,6 +1567,7 @@ static int wgrad_variant(const aq::WgradArgs &a, int MG, int NG)
     const int c4 = (a.CW + 3) / 4, jx = (a.plane + 63) / 64;
     const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
     if (a.tiles_x != 1 || !fits32) return 0;
+    if (NG == 3 && MG == 1 && c4 <= 1 && jx <= 4) return 6;  // RGB stem
     if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) return 1;
     if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) return 2;
     if (NG == 18 && c4 <= 8 && jx <= 2) return 5;  // 18 n-tiles = 288 columns = at most 32 channels
@@ -1728,6 +1729,7 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     else if (variant == 3) AQ_WGV(1, 18, 8, 3)
     else if (variant == 4) AQ_WGV(1, 18, 8, 5)
     else if (variant == 5) AQ_WGV(1, 18, 8, 2)
+    else if (variant == 6) AQ_WGV(1, 3, 1, 4)
     else if (NG == 3) AQ_WG(1, 3)
     else if (NG == 9 && MG == 1) AQ_WG(1, 9)
     else if (NG == 9) AQ_WG(2, 9)

@@ -589,7 +589,10 @@ class QResNet(nn.Module):
         an ordinary dense parameter, the arithmetic runs on the same MFMA convolution kernels."""
         c0 = self.conv0
         if c0.kernel_size == (3, 3) and c0.padding == (1, 1) and c0.stride in ((1, 1), (2, 2)) and c0.bias is None:
-            return conv3x3(x, c0.weight, c0.stride[0], None, None, stats=self.training)
+            # inside a step that defers the weight-gradient reductions the stem joins them (its gradient lands
+            # in the buffer the step registered); otherwise autograd receives the gradient as usual
+            slot = getattr(self, "_stem_slot", None) if _wgrad_deferred is not None else None
+            return conv3x3(x, c0.weight, c0.stride[0], slot, None, stats=self.training)
         return c0(x)
 
     def forward(self, x):

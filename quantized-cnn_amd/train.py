@@ -244,6 +244,14 @@ class FusedTrainStep:
         self.dp_out = None if self.fuse_adam else [torch.zeros_like(p) for p in self.ps]
         self.dq_out = [torch.zeros_like(q) if q.requires_grad else None for q in self.qs]
         self.dss = torch.full((len(self.ps),), float(config.l2_reg), dtype=torch.float32, device=dev)
+        # the stem convolution's weight gradient joins the batched slab reduction through a buffer of its own
+        c0 = getattr(model, "conv0", None)
+        self.stem_slot = self.stem_w = None
+        if isinstance(c0, nn.Conv2d) and c0.kernel_size == (3, 3) and c0.padding == (1, 1) and c0.stride in ((1, 1), (2, 2)) and c0.bias is None \
+                and c0.weight.requires_grad:
+            self.stem_w = c0.weight
+            self.stem_slot = torch.zeros_like(c0.weight)
+            model._stem_slot = self.stem_slot
         self._graphs = None
         self._key = None
         self.loss = self.reg = self.logits = None
@@ -266,15 +274,17 @@ class FusedTrainStep:
             leaves.append(w)
             l._shared = (w, slot)
         self.model._synth_cache = None
-        logits = self.model.forward_body(x)
-        # loss tail in two launches: sums of squares of the dense "weight" tensors, then cross entropy, its
-        # gradient and the loss value (the regulariser's value enters here, its gradients in phase B:
-        # 2*l2_reg*w is added to the batch gradient after the exchange, being the same on every rank)
-        dense_ss = ops.sumsq([p.detach() for p in self.dense_reg]) if self.dense_reg else None
-        vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(self.config.l2_reg), out["sumsq"], dense_ss)
+        # Weight-gradient reductions are deferred from the forward pass on (the stem looks at the switch when
+        # it runs), to one launch after the backward pass.
         jobs = []
         prev = layers.defer_wgrad_reductions(jobs, self._side if self.overlap_wgrad else None)
         try:
+            logits = self.model.forward_body(x)
+            # loss tail in two launches: sums of squares of the dense "weight" tensors, then cross entropy, its
+            # gradient and the loss value (the regulariser's value enters here, its gradients in phase B:
+            # 2*l2_reg*w is added to the batch gradient after the exchange, being the same on every rank)
+            dense_ss = ops.sumsq([p.detach() for p in self.dense_reg]) if self.dense_reg else None
+            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(self.config.l2_reg), out["sumsq"], dense_ss)
             logits.backward(dlogits)
         finally:
             layers.defer_wgrad_reductions(*prev)
@@ -282,6 +292,8 @@ class FusedTrainStep:
             torch.cuda.current_stream().wait_stream(self._side)  # join: all weight-gradient slabs written
         ops.conv_wgrad_reduce(jobs)  # the slab sums of all quantized convolutions in one launch
         del jobs
+        if self.stem_slot is not None:
+            self.stem_w.grad = self.stem_slot
         for w in leaves:
             w.grad = None
         if self._exchange:
