@@ -1128,33 +1128,74 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(const ConvArgs a, c
     }
 }
 
-// dW[i] = sum over the workgroup slabs.  A workgroup owns 32 consecutive elements; 8 thread rows
-// each add every 8th slab in ascending order, then the 8 running sums are added in order 0..7.
-__device__ __forceinline__ void wgrad_reduce_block(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab, int blk)
+// dW[i] = sum over the workgroup slabs.  8 thread rows each add every 8th slab in ascending order, then the
+// 8 running sums are added in order 0..7.  A workgroup owns 128 consecutive elements, four per thread as
+// one 16-byte load per slab (a wavefront reads two 512-byte runs), when rows of n elements keep that
+// alignment; otherwise 32 elements, one per thread.  Same order of additions either way.
+__host__ __device__ inline bool wgrad_reduce_vec(const float *part, const float *dW, int n)
 {
-    __shared__ float sh[8][33];
+    return (n & 3) == 0 && (((uintptr_t)part | (uintptr_t)dW) & 15) == 0;
+}
+__host__ __device__ inline int wgrad_reduce_blocks(const float *part, const float *dW, int n)
+{
+    return wgrad_reduce_vec(part, dW, n) ? (n + 127) / 128 : (n + 31) / 32;
+}
+
+template <int V>
+__device__ __forceinline__ void wgrad_reduce_cols(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab, int blk, float (*sh)[32 * 4 + 1])
+{
     const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const int i = blk * 32 + c;
-    float s = 0.0f;
+    const int i = (blk * 32 + c) * V;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.0f;
+    auto load = [&](int b, float (&v)[V]) {
+        if constexpr (V == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(part + (long long)b * n + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            v[0] = part[(long long)b * n + i];
+        }
+    };
     if (i < n) {
         int b = sg;
         for (; b + 56 < nslab; b += 64) {  // eight independent loads in flight, added in ascending order
-            float v[8];
+            float v[8][V];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(b + 8 * u) * n + i];
+            for (int u = 0; u < 8; ++u) load(b + 8 * u, v[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] += v[u][k];
         }
-        for (; b < nslab; b += 8) s += part[(long long)b * n + i];
+        for (; b < nslab; b += 8) {
+            float v[V];
+            load(b, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += v[k];
+        }
     }
-    sh[sg][c] = s;
+#pragma unroll
+    for (int k = 0; k < V; ++k) sh[sg][c * V + k] = s[k];
     __syncthreads();
     if (sg == 0 && i < n) {
-        float t = sh[0][c];
+        float t[V];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += sh[k][c];
-        dW[i] = t;
+        for (int k = 0; k < V; ++k) {
+            t[k] = sh[0][c * V + k];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t[k] += sh[g][c * V + k];
+        }
+        if constexpr (V == 4) *reinterpret_cast<float4 *>(dW + i) = make_float4(t[0], t[1], t[2], t[3]);
+        else dW[i] = t[0];
     }
+}
+
+__device__ __forceinline__ void wgrad_reduce_block(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab, int blk)
+{
+    __shared__ float sh[8][32 * 4 + 1];
+    if (wgrad_reduce_vec(part, dW, n)) wgrad_reduce_cols<4>(part, dW, n, nslab, blk, sh);
+    else wgrad_reduce_cols<1>(part, dW, n, nslab, blk, sh);
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int n, int nslab)
@@ -1595,7 +1636,8 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     int nslab = 0;
     if (N > 0)
         if (int rc = wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, st, &nslab)) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nW + 31) / 32), dim3(256), 0, st, static_cast<const float *>(workspace), dW, nW, nslab);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(static_cast<const float *>(workspace), dW, nW)), dim3(256), 0, st,
+                       static_cast<const float *>(workspace), dW, nW, nslab);
     return check_launch("aq_conv_wgrad(reduce)");
 }
 
@@ -1624,7 +1666,7 @@ int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
             AQ_REQUIRE(q.dW && q.n >= 1 && q.nslab >= 0 && (q.nslab == 0 || q.part), -EINVAL, "aq_conv_wgrad_reduce: bad job %d", base + j);
             t.part[j] = q.part; t.dW[j] = q.dW; t.n[j] = q.n; t.nslab[j] = q.nslab;
             t.first[j] = blocks;
-            blocks += (q.n + 31) / 32;
+            blocks += wgrad_reduce_blocks(q.part, q.dW, q.n);
         }
         t.first[t.njobs] = blocks;
         hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
