@@ -49,14 +49,30 @@ __device__ inline float block_sum(float v, float *sh)
 
 // iterate over the vectors of channel c in images [n0, n1): f(offset into the tensor)
 template <int VEC, typename F>
-__device__ inline void for_slice(int n0, int n1, int c, int C, int HW, F f)
+__device__ inline void for_slice(int n0, int n1, int c, int C, int HW, F f, int first_round = 0)
 {
     const int per = HW / VEC;
     const int total = (n1 - n0) * per;
-    for (int i = threadIdx.x; i < total; i += BN_T) {
+    for (int i = threadIdx.x + first_round * BN_T; i < total; i += BN_T) {
         const int n = i / per, k = i - n * per;
         f(((size_t)(n0 + n) * C + c) * HW + (size_t)k * VEC, n0 + n);
     }
+}
+
+// The streaming kernels first need per-channel numbers that one wavefront merges from partials (a memory
+// round trip plus cross-lane sums); their own first loads do not depend on those, so the first PRE rounds of
+// a thread's slice (all of it at the usual sizes) are requested before the merge and land during it.
+constexpr int BN_PRE = 2;
+template <int VEC>
+__device__ inline bool slice_item(int round, int n0, int n1, int c, int C, int HW, size_t &o, int &n)
+{
+    const int per = HW / VEC;
+    const int i = threadIdx.x + round * BN_T;
+    if (i >= (n1 - n0) * per) return false;
+    const int nn = i / per, k = i - nn * per;
+    n = n0 + nn;
+    o = ((size_t)n * C + c) * HW + (size_t)k * VEC;
+    return true;
 }
 
 template <int VEC>
@@ -115,18 +131,30 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
 {
     __shared__ float sc[2];
     const int c = blockIdx.y;
+    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
+    Vec<VEC> pv[BN_PRE];
+    size_t po[BN_PRE];
+    bool pok[BN_PRE];
+#pragma unroll
+    for (int u = 0; u < BN_PRE; ++u) {
+        int n;
+        pok[u] = slice_item<VEC>(u, n0, n1, c, g.C, g.HW, po[u], n);
+        if (pok[u]) pv[u] = Vec<VEC>::load(a.x + po[u]);
+    }
     bn_finalize(a, g, c, sc);
     const float scale = sc[0], shift = sc[1];
-    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int) {
-        auto v = Vec<VEC>::load(a.x + o);
+    auto apply = [&](Vec<VEC> v, size_t o) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float t = __builtin_fmaf(v[j], scale, shift);
             v[j] = RELU ? fmaxf(t, 0.0f) : t;
         }
         v.store(a.y + o);
-    });
+    };
+#pragma unroll
+    for (int u = 0; u < BN_PRE; ++u)
+        if (pok[u]) apply(pv[u], po[u]);
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int) { apply(Vec<VEC>::load(a.x + o), o); }, BN_PRE);
 }
 
 // normalisation + ReLU + mean over the plane (the network's tail: relu(bnlast(x)) followed by an
@@ -199,6 +227,28 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
 {
     __shared__ float sc[2];
     const int c = blockIdx.y;
+    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
+    const float inv_hw = 1.0f / (float)g.HW;
+    auto fetch = [&](size_t o, int n, Vec<VEC> &d, Vec<VEC> &v, Vec<VEC> &r) {
+        if (a.dpool) {
+            const float t = a.dpool[(size_t)n * g.C + c] * inv_hw;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) d[j] = t;
+        } else {
+            d = Vec<VEC>::load(a.dy + o);
+        }
+        v = Vec<VEC>::load(a.x + o);
+        if (RES) r = Vec<VEC>::load(a.res + o);
+    };
+    Vec<VEC> pd[BN_PRE], pv[BN_PRE], pr[BN_PRE];
+    size_t po[BN_PRE];
+    bool pok[BN_PRE];
+#pragma unroll
+    for (int u = 0; u < BN_PRE; ++u) {
+        int n;
+        pok[u] = slice_item<VEC>(u, n0, n1, c, g.C, g.HW, po[u], n);
+        if (pok[u]) fetch(po[u], n, pd[u], pv[u], pr[u]);
+    }
     if (threadIdx.x < 64) {
         const int s = threadIdx.x;
         float2 p = make_float2(0.0f, 0.0f);
@@ -224,26 +274,13 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
             }
         }
     }
-    __syncthreads();
-    const float cnt = (float)g.N * (float)g.HW;
-    const float k1 = sc[0] / cnt, k2 = sc[1] / cnt;
     const float mean = a.save_mean[c], rstd = a.save_rstd[c];
     float scale, shift;
     scale_shift(a.gamma[c], a.beta[c], mean, rstd, scale, shift);
-    const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
-    const float inv_hw = 1.0f / (float)g.HW;
-    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int n) {
-        Vec<VEC> d;
-        if (a.dpool) {
-            const float t = a.dpool[(size_t)n * g.C + c] * inv_hw;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) d[j] = t;
-        } else {
-            d = Vec<VEC>::load(a.dy + o);
-        }
-        auto v = Vec<VEC>::load(a.x + o);
-        Vec<VEC> r;
-        if (RES) r = Vec<VEC>::load(a.res + o);
+    __syncthreads();
+    const float cnt = (float)g.N * (float)g.HW;
+    const float k1 = sc[0] / cnt, k2 = sc[1] / cnt;
+    auto apply = [&](Vec<VEC> d, Vec<VEC> v, Vec<VEC> r, size_t o) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const bool live = !RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f;
@@ -254,7 +291,15 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
             d[j] = t;
         }
         d.store(a.dx + o);
-    });
+    };
+#pragma unroll
+    for (int u = 0; u < BN_PRE; ++u)
+        if (pok[u]) apply(pd[u], pv[u], pr[u], po[u]);
+    for_slice<VEC>(n0, n1, c, g.C, g.HW, [&](size_t o, int n) {
+        Vec<VEC> d, v, r;
+        fetch(o, n, d, v, r);
+        apply(d, v, r, o);
+    }, BN_PRE);
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
