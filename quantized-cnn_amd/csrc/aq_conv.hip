@@ -79,6 +79,12 @@ struct ConvArgs {
     int IH, IW;          // spatial size of the (undilated) input tensor
     int rs;              // step between neighbouring output pixels inside the LDS image
     int dil;             // 2 when the LDS image is the zero-dilated input (stride-2 dgrad), else 1
+    // Stride-2 dgrad by output parity (persistent kernel): dx[2a+py][2b+px] only receives the taps whose row /
+    // column parity fits, (1, 2, 2, 4 of the nine for the four classes), read from dy[a + {0,1}][b + {0,1}]; a
+    // tile holds pixels of ONE class, TH x TW in class-grid coordinates, and walks only that class's share of
+    // the k axis: no zero-dilated image, a quarter of the matrix work.  par = 1: on; tyc = row bands per class
+    // (tiles_y = 4 * tyc); halo = 1 - par (rows / columns in front of the tile in the LDS image).
+    int par, tyc, halo;
     int TW, TH, tiles_x, tiles_y;
     int pitch, rows_in, plane;
     int Kpad;
@@ -350,9 +356,21 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     const int m0 = bc.y * 16 * MT;
     AQ_STAMP(0);
 
+    const bool par = MODE == MODE_DGRAD && a.par != 0;
     for (int k = tid; k < a.Kpad; k += 256) {
         int off = 0;
-        if (k < a.K) {
+        if (par) {
+            // k = k0(class) + c * nt(class) + ti with k0 = KC * {0, 1, 3, 5}, nt = {1, 2, 2, 4}; class = 2*py + px;
+            // within a class the taps run over ky in {1} (py = 0) or {0, 2} (py = 1), then kx likewise;
+            // tap ky = 0 reads the dy row below (offset 1), ky = 1, 2 the same row
+            const int cls = k < a.KC ? 0 : (k < 3 * a.KC ? 1 : (k < 5 * a.KC ? 2 : 3));
+            const int kk = k - a.KC * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+            const int sh = cls == 0 ? 0 : (cls == 3 ? 2 : 1);
+            const int c = kk >> sh, ti = kk & ((1 << sh) - 1);
+            const int py = cls >> 1, px = cls & 1;
+            const int tiy = px ? ti >> 1 : ti, tix = px ? ti & 1 : 0;
+            off = c * a.plane + ((py && tiy == 0) ? a.pitch : 0) + ((px && tix == 0) ? 1 : 0);
+        } else if (k < a.K) {
             const int c = k / 9, tap = k - 9 * c;
             off = c * a.plane + (tap / 3) * a.pitch + (tap % 3);
         }
@@ -364,7 +382,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     for (int j = 0; j < J; ++j) {
         const int e = lane + 64 * j;
         const int r = (e * pitch_mul) >> 16;  // e / pitch, exact for e < 1024, pitch <= 65
-        int gx = e - r * a.pitch - 1;
+        int gx = e - r * a.pitch - a.halo;
         bool ok = gx >= 0;
         if (a.dil == 2) {
             ok = ok && !(gx & 1);
@@ -381,7 +399,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         const int pr = (wave * NT + t) * 16 + jn;
         const int py = pr >> tw_shift, px = pr & (a.TW - 1);
         pixbase[t] = py * a.rs * a.pitch + px * a.rs;
-        pyx[t] = px < a.OW ? ((py << 16) | px) : -1;
+        pyx[t] = px < (par ? a.OW >> 1 : a.OW) ? ((py << 16) | px) : -1;
     }
     const int chs = a.IH * a.IW;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // wavefront index as a scalar
@@ -389,8 +407,10 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     float sv[CH4][J];
     unsigned inmask = 0;  // bit j: element j of the tile being fetched lies inside the tensor
     auto fetch_tile = [&](int tile) {
-        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
-        const int r0 = ty * a.TH * a.rs - 1;
+        const int n = tile / a.tiles_y;
+        int ty = tile - n * a.tiles_y;
+        if (par) ty -= (ty / a.tyc) * a.tyc;  // row band inside its class
+        const int r0 = ty * a.TH * a.rs - a.halo;
         const __amdgpu_buffer_rsrc_t src = make_rsrc(a.in + (long long)n * a.KC * chs, (unsigned)(a.KC * chs) * 4u);
         unsigned off[J];
 #pragma unroll
@@ -465,7 +485,17 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
                 const int c = it / (16 * MT), rl = it - c * (16 * MT);
                 if (it < items) {
 #pragma unroll
-                    for (int tw = 0; tw < 9; ++tw) As[as_index(rl, c * 9 + (MODE == MODE_DGRAD ? 8 - tw : tw))] = w[u][tw];
+                    for (int tw = 0; tw < 9; ++tw) {
+                        int k = c * 9 + (MODE == MODE_DGRAD ? 8 - tw : tw);
+                        if (par) {  // tap (ky, kx) = tw of W[co, ci] goes to its parity class's share of the k axis
+                            const int ky = tw / 3, kx = tw % 3;
+                            const int py = ky != 1, px = kx != 1;
+                            const int cls = 2 * py + px, sh = py + px;
+                            const int ti = (ky == 2 ? 1 : 0) * (px ? 2 : 1) + (kx == 2 ? 1 : 0);
+                            k = a.KC * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5))) + (c << sh) + ti;
+                        }
+                        As[as_index(rl, k)] = w[u][tw];
+                    }
                 }
             }
         }
@@ -538,16 +568,17 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     }
     AQ_STAMP(7);
 
-    const int nkb = a.Kpad >> 4;
+    // k-blocks a tile walks: all of them, or (parity classes) the share of the tile's class; set per tile
+    int kb_lo = 0, nkb = a.Kpad >> 4;
     auto load_a = [&](int kb, float (&av)[MT][4]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(&As[((kb * MT + m) * 64 + lane) * 4]);
+            const float4 w4 = *reinterpret_cast<const float4 *>(&As[(((kb_lo + kb) * MT + m) * 64 + lane) * 4]);
             av[m][0] = w4.x; av[m][1] = w4.y; av[m][2] = w4.z; av[m][3] = w4.w;
         }
     };
     auto load_k = [&](int kb, int (&kof)[4]) {
-        const int4 ko = *reinterpret_cast<const int4 *>(&ktab[16 * (kb < nkb ? kb : nkb - 1) + 4 * kq]);
+        const int4 ko = *reinterpret_cast<const int4 *>(&ktab[16 * (kb_lo + (kb < nkb ? kb : nkb - 1)) + 4 * kq]);
         kof[0] = ko.x; kof[1] = ko.y; kof[2] = ko.z; kof[3] = ko.w;
     };
     auto load_b = [&](const int (&kof)[4], float (&bv)[4][NT]) {
@@ -588,7 +619,16 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
         // the epilogue's second operand (the shortcut added to the output, or the batch-norm input whose
         // backward sums are reduced) is requested now as well, not after the MFMAs
-        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
+        const int n = tile / a.tiles_y;
+        int ty = tile - n * a.tiles_y;
+        int os = 1, cpy = 0, cpx = 0;  // output pixel = os * (tile pixel) + (cpy, cpx)
+        if (par) {
+            const int cls = ty / a.tyc;
+            ty -= cls * a.tyc;
+            os = 2; cpy = cls >> 1; cpx = cls & 1;
+            kb_lo = (a.KC * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)))) >> 4;
+            nkb = (a.KC << (cpy + cpx)) >> 4;
+        }
         const int oy0 = ty * a.TH;
         const int ohw = a.OH * a.OW;
         const long long img = (long long)n * a.M * ohw;
@@ -598,7 +638,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             const __amdgpu_buffer_rsrc_t esrc = make_rsrc((bnb_on ? a.bx : a.res) + img, (unsigned)(a.M * ohw) * 4u);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+                const int oy = (oy0 + (pyx[nt] >> 16)) * os + cpy, ox = (pyx[nt] & 0xffff) * os + cpx;
                 const bool pok = pyx[nt] >= 0 && oy < a.OH;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -658,7 +698,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + img, (unsigned)(a.M * ohw) * 4u);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int oy = oy0 + (pyx[nt] >> 16), ox = pyx[nt] & 0xffff;
+            const int oy = (oy0 + (pyx[nt] >> 16)) * os + cpy, ox = (pyx[nt] & 0xffff) * os + cpx;
             const bool pok = pyx[nt] >= 0 && oy < a.OH;
 #ifdef AQ_EXPERIMENT
             if (a.dbg & 4) continue;
@@ -1248,28 +1288,43 @@ struct ConvStatsPlan {
 constexpr int CONV_STATS_MAX_PARTS = 512;  // the consumer keeps ceil(P / 64) partials per lane in registers
 
 // dry: no launch; returns 1 when the persistent kernel (the one that can normalise its input) would run
+// par: stride-2 dgrad by output parity classes (persistent kernel only); *fell = true when that kernel does not
+// take the shape, nothing launched (the caller then plans again without par)
 template <int MODE>
-static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false, ConvStatsPlan *plan = nullptr)
+static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry, ConvStatsPlan *plan, bool par, bool *fell)
 {
     if (plan) *plan = ConvStatsPlan{};
     // tile choice: NT = 2 (128 pixels) and MT up to 4, shrunk until the grid fills the chip
     const int mtiles = (a.M + 15) / 16;
     int MT = std::min(4, mtiles), NT = 2;
     if (MT == 3) MT = 2;
+    // grid the tiles are cut from: the output, or (par) one parity class of it, four of them per image
+    const int gw = par ? a.OW / 2 : a.OW, gh = par ? a.OH / 2 : a.OH, gmul = par ? 4 : 1;
+    if (par) {
+        a.par = 1; a.halo = 0; a.dil = 1; a.rs = 1;
+    } else {
+        a.par = 0; a.halo = 1;
+    }
     auto blocks = [&](int mt, int nt) {
         int TW, TH;
-        pick_tile(a.OW, 64 * nt, TW, TH);
-        return (long long)N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW) * ((mtiles + mt - 1) / mt);
+        pick_tile(gw, 64 * nt, TW, TH);
+        return (long long)N * ((gh + TH - 1) / TH) * ((gw + TW - 1) / TW) * gmul * ((mtiles + mt - 1) / mt);
     };
     while (blocks(MT, NT) < 512 && (NT > 1 || MT > 1)) {
         if (NT > 1) NT = 1;
         else MT >>= 1;
     }
-    pick_tile(a.OW, 64 * NT, a.TW, a.TH);
-    a.tiles_x = (a.OW + a.TW - 1) / a.TW;
-    a.tiles_y = (a.OH + a.TH - 1) / a.TH;
-    a.pitch = (a.TW - 1) * a.rs + 3;
-    a.rows_in = (a.TH - 1) * a.rs + 3;
+    if (NT > 1) {  // a 128-pixel tile taller than the grid would be half empty
+        int tw, th;
+        pick_tile(gw, 128, tw, th);
+        if (th > gh) NT = 1;
+    }
+    pick_tile(gw, 64 * NT, a.TW, a.TH);
+    a.tiles_x = (gw + a.TW - 1) / a.TW;
+    a.tyc = (gh + a.TH - 1) / a.TH;
+    a.tiles_y = a.tyc * gmul;
+    a.pitch = par ? a.TW + 1 : (a.TW - 1) * a.rs + 3;
+    a.rows_in = par ? a.TH + 1 : (a.TH - 1) * a.rs + 3;
     a.plane = a.rows_in * a.pitch;
     a.Kpad = (a.K + 31) & ~31;  // even number of 16-wide k-blocks (main loops are unrolled by two)
     a.vecA = (a.K % 4 == 0) && (((uintptr_t)a.W & 15) == 0);
@@ -1302,11 +1357,11 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         bool done = true;
         const bool have = !((jj == 5 && c4 > 8) || (jj == 9 && c4 > 4));
         // statistics epilogue: every pixel of every tile is an output pixel, and few enough partials
-        const bool stats_ok = have && a.TW == a.OW && a.OH % a.TH == 0 && pgrid.x <= (unsigned)CONV_STATS_MAX_PARTS;
+        const bool stats_ok = have && a.TW == gw && gh % a.TH == 0 && pgrid.x <= (unsigned)CONV_STATS_MAX_PARTS;
         if (plan && have) {
             *plan = ConvStatsPlan{stats_ok ? (int)pgrid.x : 0, (int)gx, a.TH * a.TW, 1, MT, NT, c4, jj, pitch_mul, tw_shift, pgrid.x, pgrid.y, k4n_rcp, plds};
         }
-        if (dry) return have ? 1 : 0;
+        if (dry && !(par && !have)) return have ? 1 : 0;
         AQ_REQUIRE(!(a.stat_part || a.bwd_part) || stats_ok, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
 #define AQ_P(MM, NN, CC, JJ)                                                                                                      \
     {                                                                                                                             \
@@ -1335,6 +1390,10 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
 #undef AQ_P
         if (done) return check_launch(who);
     }
+    if (par) {
+        *fell = true;
+        return 0;
+    }
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
     AQ_REQUIRE(!a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
@@ -1348,6 +1407,22 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
     else AQ_GEMM(1, 1);
 #undef AQ_GEMM
     return check_launch(who);
+}
+
+template <int MODE>
+static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false, ConvStatsPlan *plan = nullptr)
+{
+    // stride-2 dgrad: by parity classes when the class shares of the k axis are whole pairs of k-blocks
+    if (MODE == MODE_DGRAD && a.dil == 2 && a.KC % 32 == 0 && !(a.OH & 1) && !(a.OW & 1) && a.IH * 2 == a.OH && a.IW * 2 == a.OW) {
+        ConvArgs b = a;
+        bool fell = false;
+        const int rc = launch_gemm_impl<MODE>(b, N, st, who, dry, plan, true, &fell);
+        if (!fell) {
+            a = b;
+            return rc;
+        }
+    }
+    return launch_gemm_impl<MODE>(a, N, st, who, dry, plan, false, nullptr);
 }
 
 static void conv_fwd_args(ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride)
