@@ -171,6 +171,9 @@ CONV_SHAPES = [  # cin, cout, stride, H, W, N
     (16, 16, 1, 32, 32, 2), (16, 32, 2, 32, 32, 2), (32, 32, 1, 16, 16, 3), (32, 64, 2, 16, 16, 2), (64, 64, 1, 8, 8, 5),
     (3, 7, 1, 5, 5, 2), (5, 3, 2, 6, 6, 2), (16, 16, 1, 9, 9, 1), (16, 32, 2, 9, 9, 1), (64, 64, 1, 4, 4, 1),
     (17, 33, 1, 13, 7, 2), (33, 17, 2, 11, 20, 3), (1, 1, 1, 1, 1, 1), (4, 4, 2, 1, 1, 1), (8, 80, 1, 40, 36, 1),
+    # stride-2 dgrad by parity classes (Cout a multiple of 32, even H and W) with ragged class tiles, and its
+    # neighbours that fall back to the zero-dilated image (odd size / other channel counts)
+    (8, 32, 2, 24, 24, 3), (5, 64, 2, 20, 12, 2), (16, 32, 2, 2, 2, 1), (8, 32, 2, 23, 24, 2), (8, 48, 2, 24, 24, 2), (12, 96, 2, 6, 36, 1),
 ]
 
 
