@@ -197,6 +197,16 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
                    const float *save_mean, const float *save_rstd, const float *res, int N, int C, int HW,
                    unsigned flags, float *dx, float *dgamma, float *dbeta, void *workspace,
                    size_t workspace_bytes, const aq_conv_stats *dgrad_sums, void *stream);
+/* aq_bn_relu_bwd for the first BatchNorm of a block that changes dimensions: its input x also feeds the
+ * block's shortcut s = ZeroPad2d(AvgPool2d(2)(x)) (adp_qtz_fan.py:669-671, 673-677), and the gradient arriving
+ * over it is given as dshort = d loss / d s [N, C + pad_front + pad_back, H/2, W/2] instead of a tensor of x's
+ * shape: dx = BatchNorm+ReLU backward + a quarter of dshort[n, c + pad_front, y/2, x/2] (what aq_shortcut_bwd
+ * followed by aq_bn_relu_bwd(res) gives, without the intermediate tensor). */
+int aq_bn_relu_bwd_shortcut(const float *dy, const float *x, const float *gamma, const float *beta,
+                            const float *save_mean, const float *save_rstd, const float *dshort, int N, int C,
+                            int H, int Wd, int pad_front, int pad_back, unsigned flags, float *dx,
+                            float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                            const aq_conv_stats *dgrad_sums, void *stream);
 /* The network's tail `out = F.relu(self.bnlast(out)); out = self.ap(out)` (adp_qtz_fan.py:730-731, ap =
  * nn.AvgPool2d(8) on an 8x8 map, i.e. the mean over the plane) in one step: pooled[N, C] = mean over
  * H*W of [relu](batch_norm(x)); the activated tensor is never written.  Other arguments as

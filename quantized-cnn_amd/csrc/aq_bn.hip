@@ -186,6 +186,10 @@ struct BnBwdArgs {
     float2 *part;
     const float *gamma, *beta, *save_mean, *save_rstd;
     float *dgamma, *dbeta;
+    // pool_W > 0: res is not a tensor of x's shape but d loss / d s for s = ZeroPad(AvgPool2d(2)(x)), the block's
+    // shortcut (adp_qtz_fan.py:669-671), shape [N, pool_Cs, H/2, W/2] with x's channel c at c + pool_front; the
+    // gradient it sends to x[n, c, y, x'] is a quarter of its element [n, c + pool_front, y/2, x'/2]
+    int pool_W, pool_front, pool_Cs;
 };
 
 template <int VEC, bool RELU>
@@ -238,7 +242,18 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
             d = Vec<VEC>::load(a.dy + o);
         }
         v = Vec<VEC>::load(a.x + o);
-        if (RES) r = Vec<VEC>::load(a.res + o);
+        if (RES) {
+            if (a.pool_W > 0) {
+                const int k = (int)(o - ((size_t)n * g.C + c) * g.HW);
+                const int y = k / a.pool_W, x0 = k - y * a.pool_W;
+                const int Ho = (g.HW / a.pool_W) >> 1, Wo = a.pool_W >> 1;
+                const float *src = a.res + (((size_t)n * a.pool_Cs + c + a.pool_front) * Ho + (y >> 1)) * Wo;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) r[j] = ((y >> 1) < Ho && ((x0 + j) >> 1) < Wo) ? 0.25f * src[(x0 + j) >> 1] : 0.0f;
+            } else {
+                r = Vec<VEC>::load(a.res + o);
+            }
+        }
     };
     Vec<VEC> pd[BN_PRE], pv[BN_PRE], pr[BN_PRE];
     size_t po[BN_PRE];
@@ -402,7 +417,8 @@ int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, f
 
 static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, const float *gamma, const float *beta, const float *save_mean,
                        const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma, float *dbeta,
-                       void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream)
+                       void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream, int pool_W = 0, int pool_front = 0,
+                       int pool_Cs = 0)
 {
     using namespace aq;
     if (int rc = check_dims("aq_bn_relu_bwd", N, C, HW, true)) return rc;
@@ -423,8 +439,10 @@ static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, cons
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool relu = flags & AQ_BN_RELU;
-    const bool vec = HW % 4 == 0 && aligned16(x) && (!dy || aligned16(dy)) && aligned16(dx) && (!res || aligned16(res));
-    BnBwdArgs a{dpool, dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta};
+    // (a vector of four stays inside one image row when the pooled shortcut gradient is addressed)
+    const bool vec = HW % 4 == 0 && aligned16(x) && (!dy || aligned16(dy)) && aligned16(dx) && (!res || pool_W > 0 || aligned16(res)) &&
+                     (pool_W == 0 || pool_W % 4 == 0);
+    BnBwdArgs a{dpool, dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta, pool_W, pool_front, pool_Cs};
     const dim3 g1(g.S, C), g2(g.S2, C);
 #define AQ_BN_BWD(V, R)                                                                                        \
     {                                                                                                          \
@@ -447,6 +465,17 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
     AQ_REQUIRE(dy, -EFAULT, "aq_bn_relu_bwd: NULL dy");
     return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, res, N, C, HW, flags, dx, dgamma, dbeta, workspace, workspace_bytes,
                        dgrad_sums, stream);
+}
+
+int aq_bn_relu_bwd_shortcut(const float *dy, const float *x, const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
+                            const float *dshort, int N, int C, int H, int Wd, int pad_front, int pad_back, unsigned flags, float *dx, float *dgamma,
+                            float *dbeta, void *workspace, size_t workspace_bytes, const aq_conv_stats *dgrad_sums, void *stream)
+{
+    AQ_REQUIRE(dy && dshort, -EFAULT, "aq_bn_relu_bwd_shortcut: NULL pointer");
+    AQ_REQUIRE(H >= 2 && Wd >= 2 && pad_front >= 0 && pad_back >= 0 && (long long)H * Wd < (1LL << 31), -EINVAL,
+               "aq_bn_relu_bwd_shortcut: bad sizes H=%d W=%d pad=%d,%d", H, Wd, pad_front, pad_back);
+    return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, dshort, N, C, H * Wd, flags, dx, dgamma, dbeta, workspace, workspace_bytes,
+                       dgrad_sums, stream, Wd, pad_front, C + pad_front + pad_back);
 }
 
 int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta, const float *save_mean,

@@ -276,7 +276,9 @@ class _BnReluThenConv(torch.autograd.Function):
     sums the batch-norm backward needs, and that backward is left with its streaming kernel only.
     conv_stats: statistics of x left behind by the convolution that produced it; holder: dict that receives
     the statistics of y under "stats" (None: not wanted); split=True also hands x through (second output)
-    so that a shortcut's gradient is added inside the batch-norm backward kernel."""
+    so that a shortcut's gradient is added inside the batch-norm backward kernel; split=(front, back): the
+    second output is the block's shortcut ZeroPad(AvgPool2d(2)(x)) itself (adp_qtz_fan.py:669-671), whose
+    gradient the batch-norm backward kernel takes in its pooled form (no full-size intermediate)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, bn, W, stride, dW_slot, res, split, conv_stats, holder):
@@ -290,12 +292,18 @@ class _BnReluThenConv(torch.autograd.Function):
             y, holder["stats"] = ops.conv_forward(z, W, stride, res, stats=True)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, z, W)
         ctx.stride, ctx.dW_slot = stride, dW_slot
+        ctx.pads = tuple(split) if isinstance(split, tuple) else None
+        if ctx.pads is not None:
+            return y, ops.shortcut_forward(x, *ctx.pads)
         return (y, x.view_as(x)) if split else y
 
     @staticmethod
     def backward(ctx, dy, dalias=None):
         x, gamma, beta, mean, rstd, z, W = ctx.saved_tensors
         dy = dy.contiguous()
+        short = None
+        if ctx.pads is not None and dalias is not None:
+            short, dalias = (dalias.contiguous(), ctx.pads[0], ctx.pads[1]), None
         if _fused_backward_ok(ctx.dW_slot) and ctx.needs_input_grad[4]:
             dW = None
             dz, sums, ws, nslab = ops.conv_backward(dy, W, z, ctx.stride, bn=(x, gamma, beta, mean, rstd))
@@ -304,7 +312,7 @@ class _BnReluThenConv(torch.autograd.Function):
             dW = _weight_grad(z, dy, ctx.stride, ctx.dW_slot) if ctx.needs_input_grad[4] else None
             dz, sums = ops.conv_dgrad(dy, W, z.shape, ctx.stride, bn=(x, gamma, beta, mean, rstd))
         dx, dg, db = ops.bn_relu_backward(dz, x, gamma, beta, mean, rstd, res=dalias.contiguous() if dalias is not None else None,
-                                          dgrad_sums=sums)
+                                          dgrad_sums=sums, shortcut=short)
         return dx, dg, db, None, dW, None, None, (dy if ctx.needs_input_grad[7] else None), None, None, None
 
 
@@ -324,6 +332,9 @@ def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
     fused = (FUSE_BN_INTO_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
              and (bn.training or bn.running_mean is None) and ops.bnconv_supported(x.shape, W.shape[0], stride))
     if fused:
+        if isinstance(split, tuple):
+            y, xs = _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, True)
+            return y, _Shortcut.apply(xs, *split)
         return _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split)
     usual = (COUPLE_BN_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
              and (bn.training or bn.running_mean is None) and torch.is_grad_enabled())
@@ -336,7 +347,7 @@ def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
         return out
     if split:
         z, xs = bn_relu(bn, x, split=True)
-        return conv3x3(z, W, stride, dW_slot, res, stats), xs
+        return conv3x3(z, W, stride, dW_slot, res, stats), (_Shortcut.apply(xs, *split) if isinstance(split, tuple) else xs)
     return conv3x3(bn_relu(bn, x), W, stride, dW_slot, res, stats)
 
 
@@ -482,7 +493,8 @@ class QConv2d(_QuantBase):
     def forward(self, x, res=None, bn=None, split=False):
         """res: optional tensor added to the output inside the convolution kernel (the shortcut).
         bn: optional nn.BatchNorm2d whose relu(bn(x)) is the convolution's input (fused where possible);
-        with split=True returns (y, x') where x' is x for the caller's shortcut path."""
+        with split=True returns (y, x') where x' is x for the caller's shortcut path, with split=(front, back)
+        (y, s) where s is the pooled and channel-padded shortcut of x."""
         assert len(x.shape) == 4
         if self.ksize != 3 or self.padding != 1 or self.stride not in (1, 2):
             raise NotImplementedError("the HIP convolution implements ksize=3, padding=1, stride 1|2 "
@@ -497,6 +509,8 @@ class QConv2d(_QuantBase):
             x = bn_relu(bn, x)
         y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], w["q"] if "q" in w else self.q_level.detach(), self.stride)
         y = y if res is None else y + res
+        if isinstance(split, tuple):
+            return y, _Shortcut.apply(xs, *split)
         return (y, xs) if split else y
 
 
@@ -537,6 +551,11 @@ class _Block(nn.Module):
     def _residual_forward(self, x):
         """adp_qtz_fan.py:673-678.  bn1 hands x through for the shortcut so that the shortcut's gradient
         is added inside bn1's backward kernel; the shortcut itself is added inside conv2's kernel."""
+        if (not isinstance(self.shortcut, nn.Identity) and getattr(self, "_pad", None) is not None and x.is_cuda and x.dtype == torch.float32
+                and x.dim() == 4):
+            # the shortcut comes out of conv1's node, so that its gradient enters bn1's backward kernel in pooled form
+            out, s = self.conv1(x, bn=self.bn1, split=(self._pad, self._pad))
+            return self.conv2(out, res=s, bn=self.bn2)
         out, xs = self.conv1(x, bn=self.bn1, split=True)
         return self.conv2(out, res=self._apply_shortcut(xs), bn=self.bn2)
 

@@ -369,7 +369,8 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
     return y, mean, rstd
 
 
-def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True, pool=False, dgrad_sums=None):
+def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=True, need_affine_grads=True, pool=False, dgrad_sums=None,
+                     shortcut=None):
     """-> (dx [+ res], dgamma, dbeta) of bn_relu_forward in batch-statistics mode.  pool=True: dy is the
     gradient of the pooled output, shape (N, C)."""
     N, Cn, HW = _bn_dims(x)
@@ -378,6 +379,12 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
             raise ValueError("bn_relu_backward(pool): dy must be (N, C) = (%d, %d) and res None" % (N, Cn))
     elif dy.shape != x.shape or (res is not None and res.shape != x.shape):
         raise ValueError("bn_relu_backward: dy / res must have the shape of x %s" % (tuple(x.shape),))
+    if shortcut is not None:
+        # shortcut = (dshort, pad_front, pad_back): gradient of ZeroPad(AvgPool2d(2)(x)) instead of a res tensor
+        dshort, front, back = shortcut
+        if pool or res is not None or x.dim() != 4 or tuple(dshort.shape) != (N, Cn + front + back, x.shape[2] // 2, x.shape[3] // 2):
+            raise ValueError("bn_relu_backward: shortcut gradient %s does not belong to x %s with pads %d, %d" % (
+                tuple(dshort.shape), tuple(x.shape), front, back))
     dx = torch.empty_like(x)
     dg = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
     db = torch.empty(Cn, dtype=torch.float32, device=x.device) if need_affine_grads else None
@@ -388,6 +395,13 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
     else:
         nbytes, desc = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW), None
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    if shortcut is not None:
+        _lib.check(_lib.lib().aq_bn_relu_bwd_shortcut(
+            _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
+            _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), _lib.ptr(dshort, name="dshort"), N, Cn,
+            int(x.shape[2]), int(x.shape[3]), int(front), int(back), _lib.BN_RELU if relu else 0, _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),
+            ws.data_ptr(), nbytes, desc, _lib.stream()))
+        return dx, dg, db
     if pool:
         _lib.check(_lib.lib().aq_bn_relu_pool_bwd(
             _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),

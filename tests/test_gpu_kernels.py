@@ -752,3 +752,27 @@ def test_adam_step_argument_errors():
         ops.adam_step([p], [p.clone()], [p.clone()], [p.clone()], [st], 1e-3, betas=(1.0, 0.9))
     with pytest.raises(ValueError, match="elements"):
         ops.adam_step([p], [torch.zeros(3, device=DEV)], [p.clone()], [p.clone()], [st], 1e-3)
+
+
+@pytest.mark.parametrize("shape", [(128, 16, 32, 32), (4, 32, 16, 16), (2, 3, 6, 10), (3, 5, 7, 9)])
+def test_bn_backward_takes_the_pooled_shortcut_gradient(shape):
+    """aq_bn_relu_bwd_shortcut == aq_shortcut_bwd followed by aq_bn_relu_bwd(res) (bit for bit when both walk the
+    tensor the same way, i.e. for widths that are multiples of 4)."""
+    N, Cn, H, Wd = shape
+    rs = np.random.RandomState(sum(shape))
+    x = cu(rs.standard_normal(shape) * 1.2 + 0.1)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(Cn)), cu(0.2 * rs.standard_normal(Cn))
+    _, mean, rstd = ops.bn_relu_forward(x, g, b)
+    dy = cu(rs.standard_normal(shape))
+    front, back = Cn // 2, Cn - Cn // 2
+    ds = cu(rs.standard_normal((N, Cn + front + back, H // 2, Wd // 2)))
+    res = ops.shortcut_backward(ds, shape, front, back)
+    want = ops.bn_relu_backward(dy, x, g, b, mean, rstd, res=res)
+    got = ops.bn_relu_backward(dy, x, g, b, mean, rstd, shortcut=(ds, front, back))
+    for u, v in zip(got, want):
+        if Wd % 4 == 0:
+            assert torch.equal(u, v)
+        else:  # rows of another width are walked element by element, the reference call four at a time: other partial sums
+            assert (u - v).abs().max().item() <= 2e-6 * max(1.0, float(v.abs().max()))
+    with pytest.raises(ValueError, match="does not belong"):
+        ops.bn_relu_backward(dy, x, g, b, mean, rstd, shortcut=(ds, front + 1, back))
