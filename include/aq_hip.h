@@ -197,6 +197,15 @@ int aq_bn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
                    const float *save_mean, const float *save_rstd, const float *res, int N, int C, int HW,
                    unsigned flags, float *dx, float *dgamma, float *dbeta, void *workspace,
                    size_t workspace_bytes, const aq_conv_stats *dgrad_sums, void *stream);
+/* aq_bn_relu_fwd for the first BatchNorm of a block that changes dimensions: the same launch also writes the
+ * block's shortcut of the raw input, shortcut[N, C + pad_front + pad_back, H/2, W/2] =
+ * ZeroPad2d(AvgPool2d(2)(x)) (adp_qtz_fan.py:669-671, what aq_shortcut_fwd gives). */
+int aq_bn_relu_fwd_shortcut(const float *x, const float *gamma, const float *beta, float *running_mean,
+                            float *running_var, long long *num_batches_tracked, int N, int C, int H, int Wd,
+                            float eps, float momentum, unsigned flags, float *y, float *save_mean,
+                            float *save_rstd, void *workspace, size_t workspace_bytes,
+                            const aq_conv_stats *conv_stats, int pad_front, int pad_back, float *shortcut,
+                            void *stream);
 /* aq_bn_relu_bwd for the first BatchNorm of a block that changes dimensions: its input x also feeds the
  * block's shortcut s = ZeroPad2d(AvgPool2d(2)(x)) (adp_qtz_fan.py:669-671, 673-677), and the gradient arriving
  * over it is given as dshort = d loss / d s [N, C + pad_front + pad_back, H/2, W/2] instead of a tensor of x's

@@ -25,7 +25,7 @@ EXPORTS = (
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
-    "aq_bn_relu_bwd_shortcut",
+    "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut",
 )
 
 
@@ -101,6 +101,9 @@ def lib():
         L.aq_adam_step.restype = i
         L.aq_bn_relu_bwd_shortcut.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, C.c_uint, vp, vp, vp, vp, sz, C.POINTER(AqConvStats), vp]
         L.aq_bn_relu_bwd_shortcut.restype = i
+        L.aq_bn_relu_fwd_shortcut.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, C.c_uint, vp, vp, vp, vp, sz, C.POINTER(AqConvStats),
+                                              i, i, vp, vp]
+        L.aq_bn_relu_fwd_shortcut.restype = i
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_packed_bytes.argtypes = [C.c_longlong, i]

@@ -107,6 +107,10 @@ struct BnApplyArgs {
     float *y;
     BnStatsIn st;
     int eval;
+    // sout != NULL: the kernel also writes the block's shortcut of the SAME input, s = ZeroPad(AvgPool2d(2)(x))
+    // (adp_qtz_fan.py:669-671): [N, sCs, H/2, sW/2] with x's channel c at c + sfront, zeros elsewhere
+    float *sout;
+    int sW, sfront, sCs;
 };
 
 // first wavefront of a block: channel statistics -> sc[0] = scale, sc[1] = shift; block 0 of the channel
@@ -132,6 +136,26 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
     __shared__ float sc[2];
     const int c = blockIdx.y;
     const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
+    if (a.sout) {
+        // shortcut of the raw input: this block's images and channel, or (grid rows beyond C) one of the zero
+        // channels in front of / behind them; summation order of torch's avg_pool2d
+        const int H = g.HW / a.sW, Ho = H >> 1, Wo = a.sW >> 1;
+        const int per = Ho * Wo, total = (n1 - n0) * per;
+        if (c >= g.C) {
+            const int pc = c - g.C, cs = pc < a.sfront ? pc : pc + g.C;
+            for (int i = threadIdx.x; i < total; i += BN_T) {
+                const int n = i / per, k = i - n * per;
+                a.sout[((size_t)(n0 + n) * a.sCs + cs) * per + k] = 0.0f;
+            }
+            return;
+        }
+        for (int i = threadIdx.x; i < total; i += BN_T) {
+            const int n = i / per, k = i - n * per;
+            const int oy = k / Wo, ox = k - oy * Wo;
+            const float *p = a.x + (((size_t)(n0 + n) * g.C + c) * H + 2 * oy) * a.sW + 2 * ox;
+            a.sout[((size_t)(n0 + n) * a.sCs + c + a.sfront) * per + k] = (((p[0] + p[1]) + p[a.sW]) + p[a.sW + 1]) * 0.25f;
+        }
+    }
     Vec<VEC> pv[BN_PRE];
     size_t po[BN_PRE];
     bool pok[BN_PRE];
@@ -349,7 +373,7 @@ size_t aq_bn_workspace_bytes(int N, int C, int HW)
 static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                        long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
                        float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream,
-                       bool pool)
+                       bool pool, float *sout = nullptr, int sW = 0, int sfront = 0, int sback = 0)
 {
     using namespace aq;
     const bool eval = flags & AQ_BN_EVAL, relu = flags & AQ_BN_RELU;
@@ -383,8 +407,9 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
         launch_bn_stats(x, static_cast<float2 *>(workspace), g, st);
     }
     BnApplyArgs a{x, y, BnStatsIn{static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
-                                  save_mean, save_rstd, eps, momentum}, eval ? 1 : 0};
-    const dim3 grid(g.S2, C);
+                                  save_mean, save_rstd, eps, momentum}, eval ? 1 : 0, sout, sW, sfront, C + sfront + sback};
+    const dim3 grid(g.S2, sout ? C + sfront + sback : C);
+    AQ_REQUIRE(grid.y <= 65535, -E2BIG, "aq_bn_relu_fwd: more than 65535 channels");
     if (pool) {
         const dim3 pgrid((N + 3) / 4, C);
         if (relu) hipLaunchKernelGGL((bn_apply_pool_kernel<true>), pgrid, dim3(BN_T), 0, st, a, g);
@@ -404,6 +429,18 @@ int aq_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float 
 {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, flags, y, save_mean, save_rstd,
                        workspace, workspace_bytes, conv_stats, stream, false);
+}
+
+int aq_bn_relu_fwd_shortcut(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                            long long *num_batches_tracked, int N, int C, int H, int Wd, float eps, float momentum, unsigned flags, float *y,
+                            float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats,
+                            int pad_front, int pad_back, float *shortcut, void *stream)
+{
+    AQ_REQUIRE(shortcut, -EFAULT, "aq_bn_relu_fwd_shortcut: NULL shortcut");
+    AQ_REQUIRE(H >= 2 && Wd >= 2 && pad_front >= 0 && pad_back >= 0 && (long long)H * Wd < (1LL << 31), -EINVAL,
+               "aq_bn_relu_fwd_shortcut: bad sizes H=%d W=%d pad=%d,%d", H, Wd, pad_front, pad_back);
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, H * Wd, eps, momentum, flags, y, save_mean, save_rstd,
+                       workspace, workspace_bytes, conv_stats, stream, false, shortcut, Wd, pad_front, pad_back);
 }
 
 int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,

@@ -338,13 +338,15 @@ def _bn_dims(x):
 
 
 def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1,
-                    relu=True, use_running_stats=False, pool=False, conv_stats=None):
+                    relu=True, use_running_stats=False, pool=False, conv_stats=None, shortcut=None):
     """y = [relu](batch_norm(x)) over (N, H, W) of an NCHW tensor (adp_qtz_fan.py:674-675, 690, 726, 730).
     Batch-statistics mode returns (y, save_mean, save_rstd) and updates the running statistics in
     place like nn.BatchNorm2d in training mode; use_running_stats=True normalises with them instead.
     pool=True returns the mean of y over each (image, channel) plane, shape (N, C), instead of y (the
     network's tail, adp_qtz_fan.py:730-731).
-    conv_stats: the second result of conv_forward(..., stats=True) for this very x (batch-statistics mode)."""
+    conv_stats: the second result of conv_forward(..., stats=True) for this very x (batch-statistics mode).
+    shortcut=(pad_front, pad_back): the same launch also produces shortcut_forward(x, pad_front, pad_back); the
+    result is then (y, save_mean, save_rstd, s)."""
     N, Cn, HW = _bn_dims(x)
     y = torch.empty((N, Cn), dtype=torch.float32, device=x.device) if pool else torch.empty_like(x)
     flags = (_lib.BN_RELU if relu else 0) | (_lib.BN_EVAL if use_running_stats else 0)
@@ -360,6 +362,17 @@ def bn_relu_forward(x, gamma, beta, running_mean=None, running_var=None, num_bat
             nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     desc = C.byref(conv_stats[1]) if (conv_stats is not None and not use_running_stats) else None
+    if shortcut is not None:
+        front, back = shortcut
+        if pool or x.dim() != 4:
+            raise ValueError("bn_relu_forward: the shortcut goes with the plain form on an NCHW tensor")
+        s = torch.empty((N, Cn + front + back, x.shape[2] // 2, x.shape[3] // 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().aq_bn_relu_fwd_shortcut(
+            _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
+            _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), N, Cn,
+            int(x.shape[2]), int(x.shape[3]), float(eps), float(momentum), flags, _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd),
+            ws.data_ptr() if ws is not None else None, nbytes, desc, int(front), int(back), _lib.ptr(s), _lib.stream()))
+        return y, mean, rstd, s
     fn = _lib.lib().aq_bn_relu_pool_fwd if pool else _lib.lib().aq_bn_relu_fwd
     _lib.check(fn(
         _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),

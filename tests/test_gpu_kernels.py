@@ -776,3 +776,20 @@ def test_bn_backward_takes_the_pooled_shortcut_gradient(shape):
             assert (u - v).abs().max().item() <= 2e-6 * max(1.0, float(v.abs().max()))
     with pytest.raises(ValueError, match="does not belong"):
         ops.bn_relu_backward(dy, x, g, b, mean, rstd, shortcut=(ds, front + 1, back))
+
+
+@pytest.mark.parametrize("shape", [(128, 16, 32, 32), (4, 32, 16, 16), (2, 3, 6, 10), (3, 5, 7, 9)])
+def test_bn_forward_also_writes_the_shortcut(shape):
+    N, Cn, H, Wd = shape
+    rs = np.random.RandomState(sum(shape) + 1)
+    x = cu(rs.standard_normal(shape) * 1.2 + 0.1)
+    g, b = cu(1.0 + 0.2 * rs.standard_normal(Cn)), cu(0.2 * rs.standard_normal(Cn))
+    front, back = Cn // 2, Cn - Cn // 2
+    rm1, rv1 = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    y1, m1, r1 = ops.bn_relu_forward(x, g, b, rm1, rv1, None)
+    y2, m2, r2, s = ops.bn_relu_forward(x, g, b, rm2, rv2, None, shortcut=(front, back))
+    assert torch.equal(y1, y2) and torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    assert torch.equal(s, ops.shortcut_forward(x, front, back))
+    want = torch.nn.functional.pad(torch.nn.functional.avg_pool2d(x, 2), (0, 0, 0, 0, front, back))
+    assert torch.equal(s, want)
