@@ -130,13 +130,13 @@ __device__ inline void bn_finalize(const BnApplyArgs &a, const BnGeom &g, int c,
     __syncthreads();
 }
 
-template <int VEC, bool RELU>
+template <int VEC, bool RELU, bool SHORT>
 __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
 {
     __shared__ float sc[2];
     const int c = blockIdx.y;
     const int n0 = blockIdx.x * g.npb2, n1 = min(g.N, n0 + g.npb2);
-    if (a.sout) {
+    if constexpr (SHORT) {
         // shortcut of the raw input: this block's images and channel, or (grid rows beyond C) one of the zero
         // channels in front of / behind them; summation order of torch's avg_pool2d
         const int H = g.HW / a.sW, Ho = H >> 1, Wo = a.sW >> 1;
@@ -416,10 +416,15 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
         else hipLaunchKernelGGL((bn_apply_pool_kernel<false>), pgrid, dim3(BN_T), 0, st, a, g);
         return check_launch("aq_bn_relu_pool_fwd");
     }
-    if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true>), grid, dim3(BN_T), 0, st, a, g);
-    else if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, false>), grid, dim3(BN_T), 0, st, a, g);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, dim3(BN_T), 0, st, a, g);
-    else hipLaunchKernelGGL((bn_apply_kernel<1, false>), grid, dim3(BN_T), 0, st, a, g);
+    if (sout) {  // the variant that also writes the shortcut is a kernel of its own: the common one stays lean
+        if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true, true>), grid, dim3(BN_T), 0, st, a, g);
+        else if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, false, true>), grid, dim3(BN_T), 0, st, a, g);
+        else if (relu) hipLaunchKernelGGL((bn_apply_kernel<1, true, true>), grid, dim3(BN_T), 0, st, a, g);
+        else hipLaunchKernelGGL((bn_apply_kernel<1, false, true>), grid, dim3(BN_T), 0, st, a, g);
+    } else if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true, false>), grid, dim3(BN_T), 0, st, a, g);
+    else if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, false, false>), grid, dim3(BN_T), 0, st, a, g);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<1, true, false>), grid, dim3(BN_T), 0, st, a, g);
+    else hipLaunchKernelGGL((bn_apply_kernel<1, false, false>), grid, dim3(BN_T), 0, st, a, g);
     return check_launch("aq_bn_relu_fwd");
 }
 
