@@ -116,6 +116,11 @@ int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L,
 /* dx = d loss / d x  (autograd of adp_qtz_fan.py:574-601 w.r.t. the input) */
 int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd,
                   int Cout, int ksize, int stride, int pad, void *stream);
+/* dx = aq_conv_dgrad(..) + res: the input gradient of a convolution whose input also feeds an identity
+ * shortcut (`out = self.conv2(self.conv1(x)); out += x`, adp_qtz_fan.py:689-692), the gradient arriving over
+ * the shortcut added in the epilogue.  res has the shape of dx and may alias it. */
+int aq_conv_dgrad_add(const float *dy, const float *W, const float *res, float *dx, int N, int Cin, int H,
+                      int Wd, int Cout, int ksize, int stride, int pad, void *stream);
 /* aq_conv_dgrad whose input x is z = relu(batch_norm(xb)) (`self.convK(F.relu(self.bnK(x)))`,
  * adp_qtz_fan.py:674-676, 690-691): dz = d loss / d z as aq_conv_dgrad, and the epilogue also reduces what
  * the batch-norm backward of that z needs, per workgroup and channel, into `sums` ([Cin][desc->P] pairs,

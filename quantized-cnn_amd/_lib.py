@@ -25,7 +25,7 @@ EXPORTS = (
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
-    "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut",
+    "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add",
 )
 
 
@@ -76,6 +76,8 @@ def lib():
         L.aq_conv_fwd_add.argtypes = [vp, vp, vp, vp] + conv_dims + [vp]
         L.aq_conv_fwd_codes.argtypes = [vp, vp, vp, i, vp] + conv_dims + [vp]
         L.aq_conv_dgrad.argtypes = [vp, vp, vp] + conv_dims + [vp]
+        L.aq_conv_dgrad_add.argtypes = [vp, vp, vp, vp] + conv_dims + [vp]
+        L.aq_conv_dgrad_add.restype = i
         L.aq_conv_wgrad.argtypes = [vp, vp, vp] + conv_dims + [vp, sz, vp]
         L.aq_conv_wgrad_partial.argtypes = [vp, vp] + conv_dims + [vp, sz, C.POINTER(C.c_int), vp]
         L.aq_conv_wgrad_reduce.argtypes = [C.POINTER(AqWgradJob), i, vp]

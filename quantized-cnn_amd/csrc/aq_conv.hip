@@ -632,7 +632,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         const int oy0 = ty * a.TH;
         const int ohw = a.OH * a.OW;
         const long long img = (long long)n * a.M * ohw;
-        const bool eop = bnb_on || (MODE != MODE_DGRAD && a.res != nullptr);
+        const bool eop = bnb_on || a.res != nullptr;  // (the host never sets both)
         float ev[NT][MT][4];
         if (eop) {
             const __amdgpu_buffer_rsrc_t esrc = make_rsrc((bnb_on ? a.bx : a.res) + img, (unsigned)(a.M * ohw) * 4u);
@@ -710,7 +710,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
                     const int ch = m0 + 16 * m + 4 * kq + r;
                     const unsigned o = (pok && ch < a.M) ? (unsigned)(ch * ohw + oy * a.OW + ox) * 4u : BUF_OOB;
                     float v = acc[m][nt][r];
-                    if (MODE != MODE_DGRAD && a.res) v += ev[nt][m][r];
+                    if (a.res && !bnb_on) v += ev[nt][m][r];
                     buf_store(v, dst, o, 0);
                     if (stats_on) {  // the host enables this for exact tilings only: every pixel is an output
                         ssum[m][r] += v;
@@ -1517,16 +1517,29 @@ static void conv_dgrad_args(aq::ConvArgs &a, int N, int Cin, int H, int Wd, int 
     a.rs = 1; a.dil = stride;
 }
 
-int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
+static int conv_dgrad_common(const char *who, const float *dy, const float *W, const float *res, float *dx, int N, int Cin, int H, int Wd, int Cout,
+                             int ksize, int stride, int pad, void *stream)
 {
     using namespace aq;
-    if (int rc = check_conv("aq_conv_dgrad", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    if (int rc = check_conv(who, N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
     if (N == 0) return 0;
-    AQ_REQUIRE(dy && W && dx, -EFAULT, "aq_conv_dgrad: NULL pointer");
+    AQ_REQUIRE(dy && W && dx, -EFAULT, "%s: NULL pointer", who);
     ConvArgs a = {};
-    a.in = dy; a.W = W; a.out = dx;
+    a.in = dy; a.W = W; a.out = dx; a.res = res;
     conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
-    return launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), "aq_conv_dgrad");
+    return launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), who);
+}
+
+int aq_conv_dgrad(const float *dy, const float *W, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
+{
+    return conv_dgrad_common("aq_conv_dgrad", dy, W, nullptr, dx, N, Cin, H, Wd, Cout, ksize, stride, pad, stream);
+}
+
+int aq_conv_dgrad_add(const float *dy, const float *W, const float *res, float *dx, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
+                      int pad, void *stream)
+{
+    AQ_REQUIRE(res || N == 0, -EFAULT, "aq_conv_dgrad_add: NULL res");
+    return conv_dgrad_common("aq_conv_dgrad_add", dy, W, res, dx, N, Cin, H, Wd, Cout, ksize, stride, pad, stream);
 }
 
 size_t aq_conv_dgrad_bn_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)

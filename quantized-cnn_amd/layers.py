@@ -114,30 +114,36 @@ class _SynthAll(torch.autograd.Function):
 
 
 class _Conv3x3(torch.autograd.Function):
-    """y = conv3x3(x, W) [+ res]; the gradient of res is dy itself."""
+    """y = conv3x3(x, W) [+ res]; the gradient of res is dy itself.  split=True also hands x through (second
+    output) for an identity shortcut taken from the convolution's input: the gradient arriving over it is
+    added in the input-gradient kernel's epilogue instead of by a separate accumulation launch."""
 
     @staticmethod
-    def forward(ctx, x, W, stride, dW_slot, res, holder=None):
+    def forward(ctx, x, W, stride, dW_slot, res, holder=None, split=False):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
         ctx.stride, ctx.dW_slot = stride, dW_slot
         res = res.contiguous() if res is not None else None
         if holder is None:
-            return ops.conv_forward(x, W, stride, res)
-        y, holder["stats"] = ops.conv_forward(x, W, stride, res, stats=True)
-        return y
+            y = ops.conv_forward(x, W, stride, res)
+        else:
+            y, holder["stats"] = ops.conv_forward(x, W, stride, res, stats=True)
+        return (y, x.view_as(x)) if split else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        if _fused_backward_ok(ctx.dW_slot) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+        tail = (None, None, (dy if ctx.needs_input_grad[4] else None), None, None)
+        if _fused_backward_ok(ctx.dW_slot) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dalias is None:
             dx, _, ws, nslab = ops.conv_backward(dy, W, x, ctx.stride)
             _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
-            return dx, None, None, None, (dy if ctx.needs_input_grad[4] else None), None
-        dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
+            return (dx, None) + tail
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride, res=dalias.contiguous() if dalias is not None else None)
         dW = _weight_grad(x, dy, ctx.stride, ctx.dW_slot) if ctx.needs_input_grad[1] else None
-        return dx, dW, None, None, (dy if ctx.needs_input_grad[4] else None), None
+        return (dx, dW) + tail
 
 
 # Input gradient and weight-gradient slabs of a convolution as one launch (ops.conv_backward); applies when
@@ -177,15 +183,15 @@ CONV_EMITS_BN_STATS = True
 _STATS_ATTR = "_aq_conv_stats"
 
 
-def conv3x3(x, W, stride, dW_slot, res=None, stats=False):
-    """_Conv3x3 on (x, W); stats=True asks the kernel for the output's channel statistics as well."""
-    if not (stats and CONV_EMITS_BN_STATS):
-        return _Conv3x3.apply(x, W, stride, dW_slot, res)
-    holder = {}
-    y = _Conv3x3.apply(x, W, stride, dW_slot, res, holder)
-    if holder.get("stats") is not None:
+def conv3x3(x, W, stride, dW_slot, res=None, stats=False, split=False):
+    """_Conv3x3 on (x, W); stats=True asks the kernel for the output's channel statistics as well; split=True
+    returns (y, x') with x' = x for an identity shortcut."""
+    holder = {} if (stats and CONV_EMITS_BN_STATS) else None
+    out = _Conv3x3.apply(x, W, stride, dW_slot, res, holder, split)
+    y = out[0] if split else out
+    if holder is not None and holder.get("stats") is not None:
         setattr(y, _STATS_ATTR, (holder["stats"], y._version))
-    return y
+    return out
 
 
 def _stats_of(x):
@@ -509,7 +515,7 @@ class QConv2d(_QuantBase):
         if self.mode == "train":
             if bn is not None:
                 return bn_relu_conv(bn, x, w, self.stride, slot, res, split, stats=self.training)
-            return conv3x3(x, w, self.stride, slot, res, stats=self.training)
+            return conv3x3(x, w, self.stride, slot, res, stats=self.training, split=bool(split))
         xs = x
         if bn is not None:
             x = bn_relu(bn, x)
@@ -566,8 +572,10 @@ class _Block(nn.Module):
         return self.conv2(out, res=self._apply_shortcut(xs), bn=self.bn2)
 
     def _preresidual_forward(self, x):
-        """adp_qtz_fan.py:689-693"""
-        return self.conv2(self.conv1(x), res=x, bn=self.bn2)
+        """adp_qtz_fan.py:689-693.  conv1 hands x through for the shortcut, so that the shortcut's gradient is added
+        inside conv1's input-gradient kernel."""
+        out, xs = self.conv1(x, split=True)
+        return self.conv2(out, res=xs, bn=self.bn2)
 
 
 class QResNet(nn.Module):

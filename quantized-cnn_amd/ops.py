@@ -206,14 +206,21 @@ def conv_forward_codes(x, idx, q, stride=1):
     return y
 
 
-def conv_dgrad(dy, W, x_shape, stride=1, bn=None):
+def conv_dgrad(dy, W, x_shape, stride=1, bn=None, res=None):
     """dx = d loss / d x of conv_forward.  bn = (xb, gamma, beta, save_mean, save_rstd) says that x was
     relu(batch_norm(xb)): the result is then (dx, sums), where sums = (buffer, descriptor) holds the
     per-workgroup reductions that bn_relu_backward(dx, xb, ..., dgrad_sums=sums) takes in place of its own
-    reduction pass (None for shapes without that epilogue)."""
+    reduction pass (None for shapes without that epilogue).  res: tensor of x's shape added to dx in the
+    kernel's epilogue (the gradient arriving over an identity shortcut); not together with bn."""
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     if tuple(dy.shape) != conv_out_shape(x_shape, W.shape[0], stride):
         raise ValueError("conv_dgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x_shape)))
+    if res is not None:
+        if bn is not None or tuple(res.shape) != tuple(x_shape):
+            raise ValueError("conv_dgrad: res %s must have the shape of x %s and excludes bn" % (tuple(res.shape), tuple(x_shape)))
+        _lib.check(_lib.lib().aq_conv_dgrad_add(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(dx),
+                                                *_conv_dims(x_shape, W.shape[0], stride), _lib.stream()))
+        return dx
     if bn is not None:
         xb, gamma, beta, mean, rstd = bn
         if tuple(xb.shape) != tuple(x_shape) or not xb.is_contiguous():

@@ -793,3 +793,20 @@ def test_bn_forward_also_writes_the_shortcut(shape):
     assert torch.equal(s, ops.shortcut_forward(x, front, back))
     want = torch.nn.functional.pad(torch.nn.functional.avg_pool2d(x, 2), (0, 0, 0, 0, front, back))
     assert torch.equal(s, want)
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 1, 32, 128), (16, 32, 2, 32, 4), (64, 64, 1, 8, 3), (8, 80, 1, 40, 1), (5, 3, 2, 6, 2)])
+def test_conv_dgrad_adds_the_shortcut_gradient(shape):
+    """aq_conv_dgrad_add == aq_conv_dgrad + res with the addition as the last operation (bit-equal to doing it
+    afterwards); res may alias the output."""
+    cin, cout, s, H, N = shape
+    rs = np.random.RandomState(sum(shape))
+    Wd = 36 if H == 40 else H
+    W = cu(rs.standard_normal((cout, cin, 3, 3)) * 0.1)
+    xs = (N, cin, H, Wd)
+    dy = cu(rs.standard_normal(ops.conv_out_shape(xs, cout, s)))
+    res = cu(rs.standard_normal(xs))
+    want = ops.conv_dgrad(dy, W, xs, s) + res
+    assert torch.equal(ops.conv_dgrad(dy, W, xs, s, res=res), want)
+    with pytest.raises(ValueError, match="excludes bn"):
+        ops.conv_dgrad(dy, W, xs, s, res=res, bn=(res, None, None, None, None))
