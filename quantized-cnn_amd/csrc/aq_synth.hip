@@ -543,7 +543,8 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
     // streaming cache policy when the tensors cannot stay in the 256 MiB last-level cache anyway
     long long total_bytes = 0;
     for (int i = 0; i < nseg; ++i) total_bytes += segs[i].rows * (long long)segs[i].L * 4;
-    const bool stream_policy = total_bytes > (128LL << 20);
+    // (what counts is the traffic of the call: with Adam, p, m and v are each read and written)
+    const bool stream_policy = total_bytes * (adam ? 6 : 1) > (128LL << 20);
 
     // main launches: one per (lanes-per-row, memory access) class, at most MAX_SEGS segments each
     for (int G = 8; G <= 32; G <<= 1)
