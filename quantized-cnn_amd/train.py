@@ -312,7 +312,11 @@ class FusedTrainStep:
             for p in self.dense:
                 views.append(self.g_flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            torch._foreach_copy_([p.grad for p in self.dense], views)
+            if self.small_adam:
+                for p, v in zip(self.dense, views):  # the update reads (and completes) the gradients where they are
+                    p.grad = v
+            else:
+                torch._foreach_copy_([p.grad for p in self.dense], views)
         if self.dense_reg and not self.small_adam:
             torch._foreach_add_([p.grad for p in self.dense_reg], [p.detach() for p in self.dense_reg], alpha=2.0 * float(self.config.l2_reg))
         ps, qs = [p.detach() for p in self.ps], [q.detach() for q in self.qs]
