@@ -231,7 +231,7 @@ def bn_relu_pool(bn, pool, x):
     fused kernel that never writes the activated tensor."""
     ks = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size, pool.kernel_size)
     whole = (isinstance(pool, nn.AvgPool2d) and x.dim() == 4 and tuple(ks) == tuple(x.shape[2:]) and pool.padding in (0, (0, 0))
-             and x.is_cuda and x.dtype == torch.float32 and bn.weight is not None)
+             and x.is_cuda and x.dtype == torch.float32 and bn.weight is not None and not isinstance(bn, nn.SyncBatchNorm))
     if whole and (bn.training or bn.running_mean is None) and bn.momentum is not None:
         return _BnRelu.apply(x, bn.weight, bn.bias, bn, True, False, True, _stats_of(x)).view(x.shape[0], x.shape[1], 1, 1)
     if whole and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
@@ -342,14 +342,15 @@ def bn_relu_conv(bn, x, W, stride, dW_slot, res=None, split=False, stats=False):
     """conv(relu(bn(x)), W) [+ res] -> y or (y, x') with split; with FUSE_BN_INTO_CONV the fused kernel is
     used when the module is in its usual training configuration and one exists for the shape."""
     fused = (FUSE_BN_INTO_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
-             and (bn.training or bn.running_mean is None) and ops.bnconv_supported(x.shape, W.shape[0], stride))
+             and (bn.training or bn.running_mean is None) and not isinstance(bn, nn.SyncBatchNorm)
+             and ops.bnconv_supported(x.shape, W.shape[0], stride))
     if fused:
         if isinstance(split, tuple):
             y, xs = _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, True)
             return y, _Shortcut.apply(xs, *split)
         return _BnReluConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split)
     usual = (COUPLE_BN_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
-             and (bn.training or bn.running_mean is None) and torch.is_grad_enabled())
+             and (bn.training or bn.running_mean is None) and torch.is_grad_enabled() and not isinstance(bn, nn.SyncBatchNorm))
     if usual:
         holder = {} if (stats and CONV_EMITS_BN_STATS) else None
         out = _BnReluThenConv.apply(x, bn.weight, bn.bias, bn, W, stride, dW_slot, res, split, _stats_of(x), holder)
@@ -382,8 +383,10 @@ def bn_relu(bn, x, relu=True, split=False):
     726, 730).  split=True returns (z, x') where x' is x for the shortcut path."""
     if not x.is_cuda:
         raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
-    if bn.weight is None or (bn.training and bn.momentum is None) or x.dtype != torch.float32:
-        z = bn(x)  # module configurations the reference does not use: stock operator
+    if bn.weight is None or (bn.training and bn.momentum is None) or x.dtype != torch.float32 or isinstance(bn, nn.SyncBatchNorm):
+        # module configurations the reference does not use (and SyncBatchNorm, whose statistics span the
+        # process group): stock operator
+        z = bn(x)
         z = F.relu(z) if relu else z
         return (z, x) if split else z
     if bn.training or bn.running_mean is None:

@@ -361,3 +361,19 @@ def test_coupled_bn_backward_gives_the_same_training_step():
         assert torch.equal(a, b)
     for (n, a), (_, b) in zip(outs[0][2], outs[1][2]):
         assert grad_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4), n
+
+
+def test_sync_batch_norm_modules_go_to_the_stock_operator(monkeypatch):
+    """A SyncBatchNorm's statistics span the process group; the kernels here compute per-replica statistics, so
+    such a module must be run by its own forward, not by the fused kernels."""
+    import quantized_cnn_amd.layers as layers
+    bn = torch.nn.SyncBatchNorm(4).cuda().train()
+    called = []
+    monkeypatch.setattr(torch.nn.SyncBatchNorm, "forward", lambda self, x: called.append(1) or torch.nn.functional.batch_norm(
+        x, None, None, self.weight, self.bias, True, 0.1, self.eps))
+    x = torch.randn(2, 4, 8, 8, device="cuda")
+    layers.bn_relu(bn, x)
+    W = torch.randn(4, 4, 3, 3, device="cuda", requires_grad=True)
+    layers.bn_relu_conv(bn, x.requires_grad_(True), W, 1, None)
+    layers.bn_relu_pool(bn, torch.nn.AvgPool2d(8), x)
+    assert len(called) == 3
