@@ -38,6 +38,7 @@ struct SegDev {
     const float *acoef;    // {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} of this segment (fused update only)
     long long rows;
     int L, blk0;
+    int rag;  // rows whose length is no multiple of 4, all output bases 16-byte aligned: stores go through LDS (store_rows_staged)
 };
 struct AdamArgs {
     float omb1, b2, omb2, eps;  // 1-beta1, beta2, 1-beta2, eps
@@ -90,6 +91,34 @@ __device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, 
             for (int k = 0; k < 4; ++k)
                 if (4 * j + k < L) a[k] = v[k];
         }
+    }
+}
+
+// Rows of L % 4 != 0 floats (124 bytes at L = 31) start at every 4-byte phase, so a lane's four elements are an
+// unaligned 16-byte access and the ragged row end takes predicated scalars; written that way the gradient
+// kernel reaches only 3.4 TB/s.  But the 64/G rows one instruction covers are CONTIGUOUS in memory and start
+// 16-byte aligned: the wavefront puts them into LDS in (row, element) order and takes them out as one flat
+// run of aligned 16-byte pieces, one store instruction for the whole run.  R0 = first row, nrows = valid rows
+// (uniform); buf = this wavefront's 256 floats of LDS; called by all lanes.
+template <int G>
+__device__ __forceinline__ void store_rows_staged(float *__restrict__ p, long long R0, int nrows, int L, int j, int gq, int lane, const float (&v)[4],
+                                                  float *buf, bool stream)
+{
+    __builtin_amdgcn_wave_barrier();  // (scheduling only: LDS operations of one wavefront execute in order)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * j + k < L) buf[gq * L + 4 * j + k] = v[k];
+    __builtin_amdgcn_wave_barrier();
+    const int nf = nrows * L;
+    float *dst = p + R0 * (long long)L + 4 * lane;
+    if (4 * lane + 3 < nf) {
+        const f4 t = *reinterpret_cast<const f4 *>(buf + 4 * lane);
+        if (stream) __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(dst));
+        else *reinterpret_cast<f4 *>(dst) = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * lane + k < nf) dst[k] = buf[4 * lane + k];
     }
 }
 
@@ -237,6 +266,10 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     float *__restrict__ part = tab.s[si].part;
     const long long rows = tab.s[si].rows;
     const int L = tab.s[si].L;
+    __shared__ __attribute__((aligned(16))) float stage_all[MEM == 0 ? WAVES * 256 : 4];
+    float *stage = stage_all + (MEM == 0 ? wave * 256 : 0);
+    const bool rag = MEM == 0 && tab.s[si].rag != 0;
+    const bool rag_stream = tab.s[si].rag == 2;
 
     const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
     const long long row_begin = wt * tab.K * ROWS_IT;
@@ -310,20 +343,34 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                 float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
-                if (r < rows) {
-                    if (!ADAM || dp) store_elems<G, MEM>(dp, r, L, j, o);
-                    if constexpr (ADAM) {
-                        float pn2[4], mo[4], vo[4];
+                float pn2[4], mo[4], vo[4];
+                if constexpr (ADAM) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            mo[k] = __builtin_fmaf(ad.omb1, o[k] - m1[u][k], m1[u][k]);
-                            vo[k] = __builtin_fmaf(ad.omb2 * o[k], o[k], ad.b2 * m2[u][k]);
-                            const float denom = __builtin_fmaf(sqrtf(vo[k]), rbc2, ad.eps);
-                            pn2[k] = v[u][k] - step_size * (mo[k] / denom);
+                    for (int k = 0; k < 4; ++k) {
+                        mo[k] = __builtin_fmaf(ad.omb1, o[k] - m1[u][k], m1[u][k]);
+                        vo[k] = __builtin_fmaf(ad.omb2 * o[k], o[k], ad.b2 * m2[u][k]);
+                        const float denom = __builtin_fmaf(sqrtf(vo[k]), rbc2, ad.eps);
+                        pn2[k] = v[u][k] - step_size * (mo[k] / denom);
+                    }
+                }
+                if (rag) {  // uniform: the rows of this instruction leave as one aligned run (all lanes take part)
+                    const long long R0 = row0 + (long long)(ub + u) * RPP;
+                    const int nrows = (int)(rows - R0 < RPP ? (rows - R0 > 0 ? rows - R0 : 0) : RPP);
+                    if (!ADAM || dp) store_rows_staged<G>(dp, R0, nrows, L, j, gq, lane, o, stage, rag_stream);
+                    if constexpr (ADAM) {
+                        store_rows_staged<G>(const_cast<float *>(p), R0, nrows, L, j, gq, lane, pn2, stage, rag_stream);
+                        store_rows_staged<G>(am, R0, nrows, L, j, gq, lane, mo, stage, rag_stream);
+                        store_rows_staged<G>(av, R0, nrows, L, j, gq, lane, vo, stage, rag_stream);
+                    }
+                }
+                if (r < rows) {
+                    if (!rag) {
+                        if (!ADAM || dp) store_elems<G, MEM>(dp, r, L, j, o);
+                        if constexpr (ADAM) {
+                            store_elems<G, MEM>(const_cast<float *>(p), r, L, j, pn2);
+                            store_elems<G, MEM>(am, r, L, j, mo);
+                            store_elems<G, MEM>(av, r, L, j, vo);
                         }
-                        store_elems<G, MEM>(const_cast<float *>(p), r, L, j, pn2);
-                        store_elems<G, MEM>(am, r, L, j, mo);
-                        store_elems<G, MEM>(av, r, L, j, vo);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
@@ -573,6 +620,13 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                 const bool need = BWD ? s.dq != nullptr : s.sumsq != nullptr;
                 d.part = need ? reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.off[i]) : nullptr;
                 d.rows = s.rows; d.L = s.L; d.blk0 = nblocks;
+                // ragged rows leave through LDS when the rows of one instruction form a 16-byte-aligned run
+                d.rag = 0;
+                if (BWD && !v && (s.L & 3) != 0 && ((64 / G) * s.L) % 4 == 0) {
+                    bool al = (((uintptr_t)s.dp_c & 15) == 0);
+                    if (adam) al = al && (((uintptr_t)s.p_c | (uintptr_t)s.adam_m | (uintptr_t)s.adam_v) & 15) == 0;
+                    if (al) d.rag = stream_policy ? 2 : 1;
+                }
                 hard = hard || s.idx != nullptr || s.W_hard != nullptr;
                 const long long nb = (wave_tiles(s.rows, pl.K) + WAVES - 1) / WAVES;
                 AQ_REQUIRE(nb + nblocks < (1LL << 31), -E2BIG, "segment %d: too many rows for one launch", i);
