@@ -312,11 +312,13 @@ int aq_adam_step(const aq_adam_item *items, int nitems, double lr, double beta1,
  *   per 32 tensors: the `torch.sum(param**2)` terms of the dense "weight" tensors.
  * aq_ce_loss: logits [N, C] fp32, labels [N] int64 ->
  *   out[0] = mean cross entropy, out[1] = l2_reg * (sum sumsq_a[0..na) + sum sumsq_b[0..nb)), out[2] = their sum;
- *   dlogits [N, C] (may be NULL) = d out[0] / d logits = (softmax - onehot) / N.  A label outside [0, C)
- *   makes out[0] NaN. */
+ *   dlogits [N, C] (may be NULL) = grad_scale * d out[0] / d logits = grad_scale * (softmax - onehot) / N
+ *   (grad_scale = 1 / world size lets a data-parallel job SUM its gradients into the mean without a scaling
+ *   pass).  A label outside [0, C) makes out[0] NaN. */
 int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na,
-               const float *sumsq_b, int nb, float l2_reg, float *dlogits, float *out, void *stream);
+               const float *sumsq_b, int nb, float l2_reg, float grad_scale, float *dlogits, float *out,
+               void *stream);
 
 #ifdef __cplusplus
 }

@@ -124,7 +124,7 @@ def lib():
         L.aq_bnconv_wgrad_partial.argtypes = [vp, vp, vp, vp, vp, vp] + conv_dims + [vp, sz, C.POINTER(C.c_int), vp]
         L.aq_bnconv_supported.restype = L.aq_bnconv_fwd.restype = L.aq_bnconv_wgrad_partial.restype = i
         L.aq_sumsq.argtypes = [C.POINTER(vp), C.POINTER(C.c_longlong), i, vp, vp]
-        L.aq_ce_loss.argtypes = [vp, vp, i, i, vp, i, vp, i, f, vp, vp, vp]
+        L.aq_ce_loss.argtypes = [vp, vp, i, i, vp, i, vp, i, f, f, vp, vp, vp]
         L.aq_sumsq.restype = L.aq_ce_loss.restype = i
         L.aq_bn_workspace_bytes.argtypes = [i, i, i]
         L.aq_bn_workspace_bytes.restype = sz

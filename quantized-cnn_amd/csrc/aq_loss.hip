@@ -39,11 +39,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const SumsqTab t)
 
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, const long long *__restrict__ labels, int N, int C,
                                                       const float *__restrict__ ssa, int na, const float *__restrict__ ssb, int nb,
-                                                      float l2_reg, float *__restrict__ dlogits, float *__restrict__ out)
+                                                      float l2_reg, float grad_scale, float *__restrict__ dlogits, float *__restrict__ out)
 {
     __shared__ float sh[256];
     float part = 0.0f;
-    const float rN = 1.0f / (float)N;
+    const float rN = 1.0f / (float)N, rNg = rN * grad_scale;
     for (int r = threadIdx.x; r < N; r += 256) {
         const float *x = logits + (size_t)r * C;
         float m = x[0];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
         const bool ok = y >= 0 && y < C;
         part += ok ? lse - x[ok ? y : 0] : __builtin_nanf("");  // a label outside [0, C) poisons the loss
         if (dlogits)
-            for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = (expf(x[c] - lse) - ((long long)c == y ? 1.0f : 0.0f)) * rN;
+            for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = (expf(x[c] - lse) - ((long long)c == y ? 1.0f : 0.0f)) * rNg;
     }
     const float tot = block_tree_sum(part, sh);
     if (threadIdx.x == 0) {
@@ -93,13 +93,13 @@ int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *
 }
 
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na, const float *sumsq_b, int nb,
-               float l2_reg, float *dlogits, float *out, void *stream)
+               float l2_reg, float grad_scale, float *dlogits, float *out, void *stream)
 {
     using namespace aq;
     AQ_REQUIRE(N >= 1 && C >= 1 && na >= 0 && nb >= 0, -EINVAL, "aq_ce_loss: bad sizes N=%d C=%d", N, C);
     AQ_REQUIRE(logits && labels && out && (na == 0 || sumsq_a) && (nb == 0 || sumsq_b), -EFAULT, "aq_ce_loss: NULL pointer");
     hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, N, C, sumsq_a, na, sumsq_b, nb,
-                       l2_reg, dlogits, out);
+                       l2_reg, grad_scale, dlogits, out);
     return check_launch("aq_ce_loss");
 }
 

@@ -576,10 +576,10 @@ def sumsq(tensors):
     return out
 
 
-def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=True):
+def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=True, grad_scale=1.0):
     """CrossEntropyLoss (mean) + regulariser value in one launch (adp_qtz_fan.py:288-289):
     -> (vals, dlogits) with vals = [ce, l2_reg*(sum sumsq_a + sum sumsq_b), their sum] on the device and
-    dlogits = d ce / d logits (None unless need_grad)."""
+    dlogits = grad_scale * d ce / d logits (None unless need_grad)."""
     if logits.dim() != 2 or labels.shape != logits.shape[:1]:
         raise ValueError("ce_loss: logits %s / labels %s" % (tuple(logits.shape), tuple(labels.shape)))
     N, Cn = logits.shape
@@ -589,7 +589,7 @@ def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=Tr
     nb = 0 if sumsq_b is None else sumsq_b.numel()
     _lib.check(_lib.lib().aq_ce_loss(_lib.ptr(logits, name="logits"), _lib.ptr(labels, torch.int64, "labels"), int(N), int(Cn),
                                      _lib.ptr(sumsq_a, name="sumsq_a"), na, _lib.ptr(sumsq_b, name="sumsq_b"), nb, float(l2_reg),
-                                     _lib.ptr(d), _lib.ptr(vals), _lib.stream()))
+                                     float(grad_scale), _lib.ptr(d), _lib.ptr(vals), _lib.stream()))
     return vals, d
 
 

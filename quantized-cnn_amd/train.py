@@ -69,16 +69,17 @@ class DataParallel:
                 else:
                     dist.broadcast(t.data, 0, group=process_group)
 
-    def reduce_flat(self, flat):
-        """In-place mean over ranks of one flat gradient buffer (a single all-reduce)."""
+    def reduce_flat(self, flat, average=True):
+        """In-place mean (average=False: sum, for gradients already scaled by 1/world) over ranks of one flat
+        gradient buffer: a single all-reduce."""
         if self.host_staged:
             h = flat.cpu() if flat.is_cuda else flat
             self.dist.all_reduce(h, group=self.group)
             if h is not flat:
                 flat.copy_(h)
-            flat.div_(self.world)
         else:
             self.dist.all_reduce(flat, group=self.group)
+        if average:
             flat.div_(self.world)
 
     def reduce_dense(self):
@@ -284,7 +285,9 @@ class FusedTrainStep:
             # gradient and the loss value (the regulariser's value enters here, its gradients in phase B:
             # 2*l2_reg*w is added to the batch gradient after the exchange, being the same on every rank)
             dense_ss = ops.sumsq([p.detach() for p in self.dense_reg]) if self.dense_reg else None
-            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(self.config.l2_reg), out["sumsq"], dense_ss)
+            # data parallel: the loss gradient leaves scaled by 1/world, so that the exchange is a plain sum
+            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(self.config.l2_reg), out["sumsq"], dense_ss,
+                                        grad_scale=1.0 / self.dp.world if self._exchange else 1.0)
             logits.backward(dlogits)
         finally:
             layers.defer_wgrad_reductions(*prev)
@@ -350,7 +353,7 @@ class FusedTrainStep:
 
     def _comm(self):
         if self.dp is not None and self.dp.world > 1:
-            self.dp.reduce_flat(self.g_flat)
+            self.dp.reduce_flat(self.g_flat, average=False)
 
     # ---- driver ------------------------------------------------------------------------------
     def __call__(self, x, y):

@@ -60,16 +60,16 @@ def test_two_rank_training_equals_averaged_half_batches(tmp_path, graph):
     X = torch.randn(8, 3, 32, 32, generator=g).cuda()
     Y = torch.randint(0, 10, (8,), generator=g).cuda()
     step = FusedTrainStep(model, c, hint, use_graph=False)
-    # stand-in for the exchange: the averaging is done by hand below; world=2 makes phase B take the
+    # stand-in for the exchange: the sum over the two halves is done by hand below; world=2 makes phase B take the
     # dense gradients from the flat buffer, as it does in the two-rank job
     import types
-    step.dp = types.SimpleNamespace(world=2, reduce_flat=lambda flat: None)
+    step.dp = types.SimpleNamespace(world=2, reduce_flat=lambda flat, average=True: None)
     losses = []
     for _ in range(steps):
         step._phase_a(X[:4], Y[:4])
         g0, l0 = step.g_flat.clone(), float(step.loss)
         step._phase_a(X[4:], Y[4:])
-        step.g_flat.add_(g0).div_(2)
+        step.g_flat.add_(g0)  # each half's gradient leaves phase A already scaled by 1/world
         step._phase_b()
         losses.append(l0)
     hint.beta = 1

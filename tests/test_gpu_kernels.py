@@ -699,6 +699,8 @@ def test_ce_loss_and_sumsq_vs_oracle_and_torch(shape):
     lt.backward()
     assert abs(float(lt) - ce) <= 2e-6 * max(1.0, abs(ce)) and (xt.grad - d).abs().max().item() <= 5e-7
     # value only; a label out of range poisons the loss
+    _, dh = ops.ce_loss(cu(x), torch.from_numpy(y).cuda(), grad_scale=0.5)  # a power of two: exactly half
+    assert torch.equal(dh, d * 0.5)
     v2, d2 = ops.ce_loss(cu(x), torch.from_numpy(y).cuda(), need_grad=False)
     assert d2 is None and v2[0].item() == ce and v2[1].item() == 0.0
     bad = torch.from_numpy(y).cuda().clone()
