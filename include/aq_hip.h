@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 6
+#define AQ_ABI_VERSION 7
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -64,6 +64,18 @@ const char *aq_last_error(void);
  * workspace must hold aq_synth_workspace_bytes(segs, nseg, 0) bytes. */
 int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void *workspace,
                  size_t workspace_bytes, void *stream);
+
+/* aq_synth_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, results
+ * and launches as aq_synth_fwd, but the per-wavefront partial sums of sum W^2 go to a workspace inside the
+ * library (a device array of AQ_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
+ * process ends) and the call allocates nothing, on the device or through any library.  Layers whose
+ * aq_synth_workspace_bytes(segs, nseg, 0) exceeds AQ_STATIC_SCRATCH_BYTES are rejected with -E2BIG (one layer
+ * of up to ~33 M weights fits; calls without any sumsq output need no workspace at all).  All calls on one GPU
+ * share that workspace: calls that overlap in time on one GPU (different streams or threads) race on it and
+ * give wrong sumsq; nothing in it needs clearing between calls (every partial read is written first). */
+#define AQ_STATIC_SCRATCH_BYTES (2u << 20)
+int aq_synth_fwd_static(const aq_seg *segs, int nseg, float beta, unsigned flags, void *stream);
 
 /* Gradient of the synthesis: for every layer g = dW + wd*W (wd = 2*l2_reg*dLoss/dReg folds the
  * regulariser of adp_qtz_fan.py:737-754 in), then dp_c and dq as autograd derives them from

@@ -11,10 +11,11 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
+STATIC_SCRATCH_BYTES = 2 << 20
 
 EXPORTS = (
     "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
@@ -25,7 +26,7 @@ EXPORTS = (
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
-    "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add",
+    "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
 )
 
 
@@ -66,6 +67,8 @@ def lib():
         L.aq_abi_version.restype = i
         L.aq_last_error.restype = C.c_char_p
         L.aq_synth_fwd.argtypes = [C.POINTER(AqSeg), i, f, C.c_uint, vp, sz, vp]
+        L.aq_synth_fwd_static.argtypes = [C.POINTER(AqSeg), i, f, C.c_uint, vp]
+        L.aq_synth_fwd_static.restype = i
         L.aq_synth_bwd.argtypes = [C.POINTER(AqSeg), i, f, f, C.c_uint, vp, sz, vp]
         L.aq_synth_bwd_adam.argtypes = [C.POINTER(AqSeg), i, f, f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint, vp, sz, vp]
         L.aq_synth_bwd_adam.restype = i

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 namespace aq {
 
@@ -689,9 +690,50 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
     return check_launch(BWD ? "aq_synth_bwd(reduce)" : "aq_synth_fwd(reduce)");
 }
 
+// ---- workspace of the entry point that allocates nothing (aq_synth_fwd_static) -------------------------
+// A file-scope device array; every GPU the library runs on holds its own copy until the process ends.  In
+// host code the array's name is only a handle for hipGetSymbolAddress: the device address is looked up once
+// per device (with that device current) and from then on only that address is used, as a kernel argument
+// like any caller-provided workspace.
+static __device__ __align__(256) unsigned char scratch[AQ_STATIC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static void *scratch_addr[MAX_DEVICES];  // [device ordinal]; written once under scratch_mutex
+static std::mutex scratch_mutex;
+
+static int static_scratch(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    AQ_REQUIRE(e == hipSuccess, -ENODEV, "aq_synth_fwd_static: hipGetDevice failed: %s", hipGetErrorString(e));
+    AQ_REQUIRE(dev >= 0 && dev < MAX_DEVICES, -ENODEV, "aq_synth_fwd_static: device ordinal %d outside 0..%d", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_addr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        AQ_REQUIRE(e == hipSuccess && ptr != nullptr, -EIO, "aq_synth_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                   hipGetErrorString(e));
+        scratch_addr[dev] = ptr;
+    }
+    *out = scratch_addr[dev];
+    return 0;
+}
+
 } // namespace aq
 
 extern "C" {
+
+int aq_synth_fwd_static(const aq_seg *segs, int nseg, float beta, unsigned flags, void *stream)
+{
+    if (int rc = aq::validate(segs, nseg, beta, false)) return rc;
+    const size_t need = aq_synth_workspace_bytes(segs, nseg, 0);
+    AQ_REQUIRE(need <= (size_t)AQ_STATIC_SCRATCH_BYTES, -E2BIG,
+               "aq_synth_fwd_static: these layers need %zu bytes of partial sums, the static workspace holds %zu; use aq_synth_fwd",
+               need, (size_t)AQ_STATIC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    if (int rc = aq::static_scratch(&ws)) return rc;
+    return aq::run<false>(segs, nseg, beta, 0.0f, flags, ws, (size_t)AQ_STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream));
+}
 
 int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void *workspace, size_t workspace_bytes, void *stream)
 {
