@@ -2,7 +2,8 @@
 """Benchmark of the quantized-training hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; without a
+     launcher bench.py starts the N ranks itself, and refuses when fewer than N devices are visible)
 
 One "step" = one optimisation step of the quantized ResNet-20 (adp_qtz_fan flavour, 32 learned
 levels) on a synthetic CIFAR-10 shaped batch of 128 images per GPU: one synthesis launch for the 19
@@ -80,13 +81,35 @@ def kernel_rooflines(quick):
         except Exception:
             traffic = traffic2 = traffic3 = None
     a1 = rows * (4 * L + 4) / t1 / 1e9
+    # traffic: not measured in this run; the committed PMC result for the same launch (FETCH_SIZE x 2 + WRITE_SIZE)
+    src = "profiles/roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
     roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
     more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false, false>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": traffic2, "bytes_per_row": 8 * L + 4, "rows_per_launch": rows,
              "avg_launch_ms": round(t2 * 1e3, 4)}]
+    # the code-emitting forward (hard mode: W, 1-byte code and q[code] per row; always exact arithmetic)
+    idx_out = ops.synth_forward([p], [q], 4.0, soft=True, codes=True)
+    del idx_out
+    th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, codes=True), 10)
+    ah = rows * (4 * L + 9) / th / 1e9
+    more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true> (codes + W + q[code], exact arithmetic)", "achieved": round(ah, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "bytes_per_row": 4 * L + 9, "rows_per_launch": rows,
+                 "avg_launch_ms": round(th * 1e3, 4)})
+    # 31 levels (adp_qtz_fix): 124-byte rows, no 16-byte alignment
+    L31 = 31
+    p31 = p.view(-1)[:rows * L31].view(rows, L31)
+    q31 = torch.cat([q[:15], torch.zeros(1, device=dev), q[17:]]).contiguous()
+    dp31 = [dp[0].view(-1)[:rows * L31].view(rows, L31)]
+    t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 10)
+    t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 10)
+    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 0, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 0, false, false> (L = 31)", t31b, 8 * L31 + 4)):
+        aa = rows * bpr / tt / 1e9
+        more.append({"bound": "hbm", "kernel": nm, "achieved": round(aa, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(aa / HBM_PEAK_GBS, 4),
+                     "bytes_per_row": bpr, "rows_per_launch": rows, "avg_launch_ms": round(tt * 1e3, 4)})
+    del p31, dp31
     # the same kernel with the Adam update of p_c fused in: p, m, v read and written, 24L+4 bytes per row
     del dp
     m1, m2, stp = torch.zeros_like(p), torch.zeros_like(p), torch.zeros((), device=dev)
@@ -130,19 +153,58 @@ def cpu_baseline(quick):
     torch.set_num_threads(nthreads)
     torch.manual_seed(0)
     out = {}
-    for impl, steps in (("conv2d", 3 if not quick else 1), ("taps", 2 if not quick else 1)):
+    for impl, warm, steps in (("conv2d", 5 if not quick else 1, 20 if not quick else 2), ("taps", 1, 2 if not quick else 1)):
         model = TP.PortModel("fan", 32, conv_impl=impl)
         model.train()
         opts = TP.optimizers(model)
         x, y = torch.randn(BATCH, 3, 32, 32), torch.randint(0, 10, (BATCH,))
-        TP.train_step(model, opts, x, y)  # warm-up
+        for _ in range(warm):
+            TP.train_step(model, opts, x, y)
         t0 = time.perf_counter()
         for _ in range(steps):
             TP.train_step(model, opts, x, y)
         out[impl] = BATCH * steps / (time.perf_counter() - t0)
-    return {"value": round(out["conv2d"], 1), "unit": "img/s", "cores": nthreads, "kind": "port",
-            "sample": "3 steps of the same workload (batch 128) after 1 warm-up step, torch CPU fp32, F.conv2d formulation",
-            "value_nine_tap_formulation": round(out["taps"], 1)}
+    res = {"value": round(out["conv2d"], 1), "unit": "img/s", "cores": nthreads, "kind": "port",
+           "sample": "20 steps of the same workload (batch 128) after 5 warm-up steps, torch CPU fp32, F.conv2d formulation "
+                     "(the reference's nine-tap gather formulation: 2 steps after 1)",
+           "value_nine_tap_formulation": round(out["taps"], 1)}
+    # the quantize kernels on the CPU (C restatement, OpenMP over rows), same algorithmic byte counts as the GPU figures
+    import numpy as np
+    from oracle import oracle as O
+    O.set_num_threads(nthreads)
+    elems = 25_000_000 if not quick else 2_000_000
+    sweep = []
+    rs = np.random.RandomState(0)
+    for L in (32, 31):
+        rows = elems // L
+        p = rs.random_sample((rows, L)).astype(np.float32)
+        q = (O.levels_hint(0.3, 32) if L == 32 else O.levels_fix(0.3, 32)).astype(np.float32)
+        dW = rs.standard_normal(rows).astype(np.float32)
+        O.synth_fwd(p[:1000], q, 4.0)
+        t0 = time.perf_counter(); O.synth_fwd(p, q, 4.0, want_idx=False); tf = time.perf_counter() - t0
+        t0 = time.perf_counter(); O.synth_bwd(p, q, 4.0, dW, 1e-3); tb = time.perf_counter() - t0
+        sweep.append({"L": L, "rows": rows, "synth_fwd_GBps": round(rows * (4 * L + 4) / tf / 1e9, 2),
+                      "synth_bwd_GBps": round(rows * (8 * L + 4) / tb / 1e9, 2)})
+    res["quantize_kernels_cpu"] = {"cores": O.num_threads(), "elements": elems, "sweep": sweep}
+    return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run
+    and hand on their exit code.  The parent never initialises the GPU (device_count() alone does not)."""
+    import socket
+    import subprocess
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        raise SystemExit("bench.py: --gpus %d asked for but only %d HIP device(s) visible; not running a smaller job under that name"
+                         % (args.gpus, n))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -153,21 +215,26 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--quick", action="store_true", help="smaller roofline tensor and CPU sample (development)")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline and cpu_baseline measurements")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-GPU form of the step (two HIP graphs around an RCCL all-reduce) even on one GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)  # before anything touches the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d of the launcher" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import quantized_cnn_amd.adp_qtz_fan as fan
     from quantized_cnn_amd.train import DataParallel, FusedTrainStep
@@ -177,11 +244,11 @@ def main():
     torch.manual_seed(0)
     model = fan.ResNet(c, 3).cuda()
     model.train()
-    dp = DataParallel(model) if world > 1 else None
+    dp = DataParallel(model) if dist is not None else None
     g = torch.Generator(device="cuda").manual_seed(1000 + rank)
     x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
     y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
-    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph)
+    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None)
 
     step(x, y)
     bufs = step.static_inputs()
@@ -216,7 +283,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: quantized ResNet-20 (adp_qtz_fan: 19 layers x 32 learned levels, soft "
                                    "assignment) on synthetic CIFAR-10 32x32, full step fwd+CE+model_loss+bwd+3xAdam",
                        "global_batch": world * BATCH, "per_gpu_batch": BATCH, "parallelism": "dp%d" % world,
-                       "hip_graphs": not args.no_graph},
+                       "hip_graphs": not args.no_graph, "exchange": "rccl all-reduce of the flat dW buffer" if dp is not None else "none"},
             "final_loss": round(loss, 5),
         }
         if not args.skip_extras:

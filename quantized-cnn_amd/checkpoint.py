@@ -59,14 +59,25 @@ def _load_optimizer(opt, state):
     counters on the CPU accordingly.  The switches describe how this process runs the update, not the
     training state: keep this optimizer's own and put the counters where they then belong."""
     keep = [{k: g.get(k) for k in ("fused", "capturable", "foreach")} for g in opt.param_groups]
+    # State tensors that already exist keep their storage: a step object that has captured its HIP graphs holds
+    # their addresses (Adam kernels, the fused synthesis-gradient update), so the loaded values are copied INTO
+    # them; load_state_dict alone would leave the graphs updating orphaned tensors.
+    old = {p: dict(st) for p, st in opt.state.items()}
     opt.load_state_dict(state)
     for g, flags in zip(opt.param_groups, keep):
         g.update(flags)
-        if flags.get("fused") or flags.get("capturable"):
-            for p in g["params"]:
-                st = opt.state.get(p)
-                if st and "step" in st:
-                    st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device)
+        for p in g["params"]:
+            st = opt.state.get(p)
+            if not st:
+                continue
+            if (flags.get("fused") or flags.get("capturable")) and "step" in st:
+                st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device)
+            for k, prev in old.get(p, {}).items():
+                new = st.get(k)
+                if isinstance(prev, torch.Tensor) and isinstance(new, torch.Tensor) and prev.shape == new.shape and prev.dtype == new.dtype \
+                        and prev.device == new.device and prev.data_ptr() != new.data_ptr():
+                    prev.copy_(new)
+                    st[k] = prev
 
 
 def save_checkpoint(path, model, opts, beta, epoch, iter_idx, best_val_acc):

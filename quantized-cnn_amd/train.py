@@ -147,6 +147,7 @@ class TrainStep:
     def _capture(self, x, y):
         """Parameters and optimizer state are updated by the warm-up iterations, exactly as eager
         steps would; afterwards every replay is one more step."""
+        _refuse_sync_bn_under_capture(self.model, self.dp)
         if self.dp is not None and self.dp.world > 1:
             raise RuntimeError("graph capture of the data-parallel step is not supported; use use_graph=False")
         self._sx, self._sy = x.clone(), y.clone()
@@ -176,15 +177,28 @@ class TrainStep:
         self._graph = g
 
 
+def _refuse_sync_bn_under_capture(model, dp):
+    """SyncBatchNorm runs torch.distributed collectives inside its forward and backward; captured into a HIP
+    graph they would be replayed outside the process group's ordering.  Such a model runs eagerly."""
+    if dp is not None and dp.world > 1 and any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()):
+        raise RuntimeError("the model holds SyncBatchNorm modules (DataParallel(sync_bn=True)): their collectives cannot be "
+                           "captured in a HIP graph; build the step with use_graph=False")
+
+
 def beta_schedule(config, epoch, beta, opts):
-    """Per-epoch schedule of the reference (adp_qtz_fan.py:269-278): beta steps at epoch_list[1..3],
-    learning rates divided by 5 at epoch_list[4].  Returns the new beta."""
+    """Per-epoch schedule of the reference (adp_qtz_fan.py:269-278), to be called at the top of every epoch: beta
+    steps to beta_list[k] at epoch_list[k] (k = 1, 2, 3), learning rates of the three optimizers are divided by 5
+    at epoch_list[4].  One chain of alternatives, as in the reference: an epoch listed twice takes the first
+    match only.  Returns the new beta."""
     beta_list = list(map(int, config.beta_list.strip("[]").split(",")))
     epoch_list = list(map(int, config.epoch_list.strip("[]").split(",")))
-    for k in (1, 2, 3):
-        if epoch == epoch_list[k]:
-            beta = beta_list[k]
-    if epoch == epoch_list[4]:
+    if epoch == epoch_list[1]:
+        beta = beta_list[1]
+    elif epoch == epoch_list[2]:
+        beta = beta_list[2]
+    elif epoch == epoch_list[3]:
+        beta = beta_list[3]
+    elif epoch == epoch_list[4]:
         for o in opts:
             o.param_groups[0]["lr"] /= 5
     return beta
@@ -205,8 +219,11 @@ class FusedTrainStep:
     holding both phases when there is no exchange); with use_graph=False the same two phases run eagerly.
     """
 
-    def __init__(self, model, config, module, dp=None, use_graph=True, fuse_adam=True, overlap_wgrad=False):
-        """fuse_adam: apply optimizer_prim's Adam update of p_c inside the synthesis-gradient kernel (the
+    def __init__(self, model, config, module, dp=None, use_graph=True, fuse_adam=True, overlap_wgrad=False, force_exchange=False):
+        """force_exchange: keep the exchange (the flat-buffer all-reduce between the two graphs) even when the
+        process group has a single rank, where it changes no value: the path a multi-GPU job takes, runnable
+        on one GPU.
+        fuse_adam: apply optimizer_prim's Adam update of p_c inside the synthesis-gradient kernel (the
         optimizer object keeps its state tensors and state_dict format; its step() is not called).
         overlap_wgrad: run the weight-gradient kernels on a second HIP stream beside the rest of the
         backward pass (a parallel branch of the captured graph).  Off by default: replaying a graph with
@@ -215,6 +232,9 @@ class FusedTrainStep:
         self.overlap_wgrad = bool(overlap_wgrad)
         self._side = torch.cuda.Stream() if self.overlap_wgrad else None
         self.model, self.config, self.module, self.dp = model, config, module, dp
+        if force_exchange and dp is None:
+            raise ValueError("force_exchange needs a DataParallel object (dp=...) to run the exchange with")
+        self.force_exchange = bool(force_exchange)
         self.use_graph = use_graph
         self.criterion = nn.CrossEntropyLoss()
         self.opts = make_optimizers(model, config, capturable=use_graph, fused=True)
@@ -252,14 +272,13 @@ class FusedTrainStep:
                 and c0.weight.requires_grad:
             self.stem_w = c0.weight
             self.stem_slot = torch.zeros_like(c0.weight)
-            model._stem_slot = self.stem_slot
         self._graphs = None
         self._key = None
         self.loss = self.reg = self.logits = None
 
     @property
     def _exchange(self):
-        return self.dp is not None and self.dp.world > 1
+        return self.dp is not None and (self.dp.world > 1 or self.force_exchange)
 
     # ---- the two phases ---------------------------------------------------------------------
     def _phase_a(self, x, y):
@@ -267,6 +286,8 @@ class FusedTrainStep:
         beta = float(self.module.beta)
         for p in self.dense:
             p.grad = None  # autograd then assigns instead of launching one accumulate kernel per tensor
+        # the stem's weight gradient lands in THIS step's buffer (several step objects may share one model)
+        self.model._stem_slot = self.stem_slot
         out = ops.synth_forward([p.detach() for p in self.ps], [q.detach() for q in self.qs], beta, soft=True, sumsq=True,
                                 out_W=self.Ws)
         leaves = []
@@ -308,7 +329,7 @@ class FusedTrainStep:
     def _phase_b(self):
         from . import ops
         need_dq = [q.requires_grad for q in self.qs]
-        if self.dp is not None and self.dp.world > 1:
+        if self._exchange:
             # dense gradients come back from the exchange buffer (averaged over ranks)
             off = self.nW
             views = []
@@ -352,7 +373,7 @@ class FusedTrainStep:
             o.step()
 
     def _comm(self):
-        if self.dp is not None and self.dp.world > 1:
+        if self._exchange:
             self.dp.reduce_flat(self.g_flat, average=False)
 
     # ---- driver ------------------------------------------------------------------------------
@@ -376,6 +397,12 @@ class FusedTrainStep:
             self._graphs[1].replay()
         return self.loss
 
+    def invalidate(self):
+        """Drop the captured graphs; the next call captures again.  Needed after anything that replaces tensors
+        the graphs hold addresses of (parameters or optimizer state re-created, not copied into)."""
+        self._graphs = None
+        self._key = None
+
     def static_inputs(self):
         """(x, y) buffers the captured graphs read, or None before the first graph step.  A producer that
         writes a batch straight into them (and passes these very tensors to the step) saves the two copies
@@ -394,6 +421,7 @@ class FusedTrainStep:
                         o.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
     def _capture(self, x, y):
+        _refuse_sync_bn_under_capture(self.model, self.dp)
         self._sx, self._sy = x.clone(), y.clone()
         self._ensure_adam_state()
         for q, g in zip(self.qs, self.dq_out):

@@ -3,6 +3,10 @@
 mode "cpu": exercises DataParallel's exchange logic on CPU tensors (no kernels involved).
 mode "gpu": runs FusedTrainStep with the gradient exchange on cuda:0 (all ranks share the one GPU
             of the test box; the backend is gloo, the production backend is "nccl" = RCCL).
+mode "gpu_eval" / "gpu_syncbn": one step with separate (unfused) gradients kept, BatchNorm on running statistics
+            resp. as SyncBatchNorm: in both the two half batches must reproduce a full-batch single-process step.
+mode "nccl1": a single rank on the RCCL backend; the two-graphs-around-an-all-reduce form of the step (forced at
+            world size 1) against the one-graph form, bit for bit.
 Writes its results to <out>.rank<r>.pt
 """
 import argparse
@@ -34,7 +38,11 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if a.mode == "nccl1":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from quantized_cnn_amd.train import DataParallel, FusedTrainStep
     from quantized_cnn_amd import layers
     res = {}
@@ -54,6 +62,55 @@ def main():
         res["dense_names"] = [n for n, p in m.named_parameters() if "p_c" not in n and "q_level" not in n]
         dp.close()
         assert layers._dW_reduce_hook is None
+    elif a.mode == "nccl1":
+        import quantized_cnn_amd.adp_qtz_fan as fan
+        c = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,
+                               prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+        fan.beta = 1
+        g = torch.Generator().manual_seed(5)
+        x, y = torch.randn(16, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (16,), generator=g).cuda()
+        runs = []
+        for force in (False, True):
+            torch.manual_seed(3)
+            model = fan.ResNet(c, 3).cuda().train()
+            dp = DataParallel(model)
+            step = FusedTrainStep(model, c, fan, dp=dp, use_graph=bool(a.graph), force_exchange=force)
+            assert step._exchange == force
+            losses = [float(step(x, y)) for _ in range(a.steps)]
+            if a.graph:
+                assert (step._graphs[1] is not None) == force  # two graphs around the all-reduce / one graph
+            runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+            dp.close()
+        res["losses"], res["losses_forced"] = runs[0][0], runs[1][0]
+        res["equal"] = all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
+        res["backend"] = dist.get_backend()
+    elif a.mode in ("gpu_eval", "gpu_syncbn"):
+        import quantized_cnn_amd.adp_qtz_hint as hint
+        c = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,
+                               prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+        hint.beta = 2
+        torch.manual_seed(7)
+        model = hint.ResNet(c, [0.1 * (i + 1) for i in range(20)], torch.zeros(10)).cuda().train()
+        if a.mode == "gpu_eval":
+            for m in model.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        dp = DataParallel(model, sync_bn=(a.mode == "gpu_syncbn"))
+        if a.mode == "gpu_syncbn":
+            assert any(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
+            try:
+                FusedTrainStep(model, c, hint, dp=dp, use_graph=True)(torch.zeros(2, 3, 32, 32).cuda(), torch.zeros(2, dtype=torch.long).cuda())
+                res["graph_refused"] = False
+            except RuntimeError as e:
+                res["graph_refused"] = "SyncBatchNorm" in str(e)
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(world * 4, 3, 32, 32, generator=g)
+        Y = torch.randint(0, 10, (world * 4,), generator=g)
+        x, y = X[rank * 4:(rank + 1) * 4].cuda(), Y[rank * 4:(rank + 1) * 4].cuda()
+        step = FusedTrainStep(model, c, hint, dp=dp, use_graph=False, fuse_adam=False)
+        res["loss"] = float(step(x, y))
+        res["reg"] = float(step.reg)
+        res["grads"] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
     else:
         import quantized_cnn_amd.adp_qtz_hint as hint
         c = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,

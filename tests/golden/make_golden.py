@@ -333,61 +333,113 @@ def fill_model_from_numpy(torch, model, seed):
             p.copy_(torch.from_numpy(a.astype(np.float32)).reshape(p.shape))
 
 
+def relu_margin(torch, model, x):
+    """Smallest |pre-activation| of one training-mode forward pass: every BatchNorm output of these models feeds a
+    ReLU (adp_qtz_fan.py:674-675, 690, 726, 730).  The pass runs without grad on a copy of the buffers' state."""
+    vals = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: vals.append(float(out.detach().abs().min())))
+             for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    saved = [b.clone() for b in model.buffers()]
+    with torch.no_grad():
+        model.forward(x)
+    for b, v in zip(model.buffers(), saved):
+        b.copy_(v)
+    for h in hooks:
+        h.remove()
+    return min(vals)
+
+
 def gen_train(torch):
     """Five optimisation steps (fwd + CE + model_loss + bwd + 3x Adam) of each variant's full
-    ResNet-20 on a fixed synthetic batch; stores losses, logits and parameter checksums."""
+    ResNet-20 on a fixed synthetic batch; stores losses, logits and parameter checksums.
+
+    Batch 8: the batch is drawn (seed after seed) until no ReLU input of the first forward pass lies within
+    RELU_MARGIN of zero, so that another correct fp32 evaluation (other summation order, ~1e-6 of the activation
+    scale) takes the same side of every ReLU and first-step gradients can be compared tightly; the margin found
+    is stored.  Batch 128 (the benchmark's batch): loss curve, first logits and regulariser only; its inputs are
+    re-derived at test time from the stored numpy RandomState seed (legacy stream, frozen by numpy's policy)."""
     out = {}
     steps, B = 5, 8
+    RELU_MARGIN = 3e-6
     for variant in ("fan", "fix", "hint"):
         mod = load_ref("adp_qtz_%s.py" % variant)
         c = cfg()
         mod.config = c
-        mod.beta = 1
         rs = np.random.RandomState(7)
         s = [float(v) for v in np.exp(rs.uniform(np.log(0.1), np.log(2.0), 20))]
         v = torch.from_numpy((0.1 * rs.standard_normal(10)).astype(np.float32))
-        torch.manual_seed(0)
-        model = mod.ResNet(c, 3) if variant == "fan" else mod.ResNet(c, s, v)
-        model._keep_q = variant != "fan"
-        fill_model_from_numpy(torch, model, 11)
-        model.train()
-        x = torch.from_numpy(rs.standard_normal((B, 3, 32, 32)).astype(np.float32))
-        y = torch.from_numpy(rs.randint(0, 10, B).astype(np.int64))
-        named = list(model.named_parameters())
-        o1 = torch.optim.Adam([p for n, p in named if "p_c" in n], lr=1e-2)
-        o2 = torch.optim.Adam([p for n, p in named if "q_level" in n], lr=1e-3)
-        o3 = torch.optim.Adam([p for n, p in named if "p_c" not in n and "q_level" not in n], lr=1e-2)
-        crit = torch.nn.CrossEntropyLoss()
-        losses, regs, logit0 = [], [], None
-        for it in range(steps):
-            if it == 3:
-                mod.beta = 2  # exercise the sharpening-factor change
-            logits = model.forward(x)
-            reg = mod.model_loss(c, mod.beta, model)
-            loss = crit(logits, y) + reg
-            loss.backward()
-            if it == 0:
-                logit0 = logits.detach().numpy().copy()
-                g0 = {n: (None if p.grad is None else p.grad.detach().numpy().copy()) for n, p in named}
-            o1.step(); o2.step(); o3.step()
-            o1.zero_grad(); o2.zero_grad(); o3.zero_grad()
-            losses.append(loss.item()); regs.append(reg.item())
-        k = variant + "_"
-        out[k + "s"] = np.array(s); out[k + "v"] = f32(v.numpy())
-        out[k + "x"] = f32(x.numpy()); out[k + "y"] = y.numpy()
-        out[k + "loss"] = np.array(losses); out[k + "reg"] = np.array(regs); out[k + "logits0"] = f32(logit0)
-        for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
-            out[k + "q_final_" + n] = f32(dict(named)[n + ".q_level"].detach().numpy())
-            gq = g0[n + ".q_level"]
-            out[k + "dq0_" + n] = np.zeros(0, np.float32) if gq is None else f32(gq)
-            out[k + "dp0_head_" + n] = f32(g0[n + ".p_c"].reshape(-1)[:4096])
-            out[k + "p_final_head_" + n] = f32(dict(named)[n + ".p_c"].detach().numpy().reshape(-1)[:4096])
-        out[k + "g0_conv0"] = f32(g0["conv0.weight"]); out[k + "g0_bias"] = f32(g0["linear.bias"])
-        out[k + "g0_bn0_w"] = f32(g0["bn0.weight"])
-        out[k + "keys"] = np.array(list(model.state_dict().keys()))
-        out[k + "param_names"] = np.array([n for n, _ in named])
-        out[k + "p_sum"] = np.array([float(p.detach().double().sum()) for n, p in named])
-        print(variant, "losses", losses)
+        for tag, batch in (("", B), ("b128_", 128)):
+            mod.beta = 1
+            torch.manual_seed(0)
+            model = mod.ResNet(c, 3) if variant == "fan" else mod.ResNet(c, s, v)
+            model._keep_q = variant != "fan"
+            fill_model_from_numpy(torch, model, 11)
+            model.train()
+            if batch == B:
+                best = (-1.0, None)
+                for xseed in range(1000, 4000):
+                    rx = np.random.RandomState(xseed)
+                    x = torch.from_numpy(rx.standard_normal((batch, 3, 32, 32)).astype(np.float32))
+                    y = torch.from_numpy(rx.randint(0, 10, batch).astype(np.int64))
+                    m = relu_margin(torch, model, x)
+                    if m > best[0]:
+                        best = (m, xseed)
+                    if m >= RELU_MARGIN:
+                        break
+                margin, xseed = best
+                rx = np.random.RandomState(xseed)
+                x = torch.from_numpy(rx.standard_normal((batch, 3, 32, 32)).astype(np.float32))
+                y = torch.from_numpy(rx.randint(0, 10, batch).astype(np.int64))
+                print(variant, "batch 8: x seed", xseed, "relu margin %.3g" % margin)
+            else:
+                xseed = 500
+                rx = np.random.RandomState(xseed)
+                x = torch.from_numpy(rx.standard_normal((batch, 3, 32, 32)).astype(np.float32))
+                y = torch.from_numpy(rx.randint(0, 10, batch).astype(np.int64))
+            named = list(model.named_parameters())
+            o1 = torch.optim.Adam([p for n, p in named if "p_c" in n], lr=1e-2)
+            o2 = torch.optim.Adam([p for n, p in named if "q_level" in n], lr=1e-3)
+            o3 = torch.optim.Adam([p for n, p in named if "p_c" not in n and "q_level" not in n], lr=1e-2)
+            crit = torch.nn.CrossEntropyLoss()
+            losses, regs, logit0 = [], [], None
+            for it in range(steps):
+                if it == 3:
+                    mod.beta = 2  # exercise the sharpening-factor change
+                logits = model.forward(x)
+                reg = mod.model_loss(c, mod.beta, model)
+                loss = crit(logits, y) + reg
+                loss.backward()
+                if it == 0:
+                    logit0 = logits.detach().numpy().copy()
+                    g0 = {n: (None if p.grad is None else p.grad.detach().numpy().copy()) for n, p in named}
+                o1.step(); o2.step(); o3.step()
+                o1.zero_grad(); o2.zero_grad(); o3.zero_grad()
+                losses.append(loss.item()); regs.append(reg.item())
+            k = variant + "_" + tag
+            out[k + "loss"] = np.array(losses); out[k + "reg"] = np.array(regs); out[k + "logits0"] = f32(logit0)
+            out[k + "xseed"] = np.int64(xseed)
+            out[k + "p_sum"] = np.array([float(p.detach().double().sum()) for n, p in named])
+            print(variant, tag, "losses", losses)
+            if batch != B:
+                continue
+            out[k + "relu_margin"] = np.float64(margin)
+            out[k + "s"] = np.array(s); out[k + "v"] = f32(v.numpy())
+            out[k + "x"] = f32(x.numpy()); out[k + "y"] = y.numpy()
+            for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
+                out[k + "q_final_" + n] = f32(dict(named)[n + ".q_level"].detach().numpy())
+                gq = g0[n + ".q_level"]
+                out[k + "dq0_" + n] = np.zeros(0, np.float32) if gq is None else f32(gq)
+                out[k + "dp0_head_" + n] = f32(g0[n + ".p_c"].reshape(-1)[:4096])
+                out[k + "p_final_head_" + n] = f32(dict(named)[n + ".p_c"].detach().numpy().reshape(-1)[:4096])
+            out[k + "g0_conv0"] = f32(g0["conv0.weight"]); out[k + "g0_bias"] = f32(g0["linear.bias"])
+            out[k + "g0_bn0_w"] = f32(g0["bn0.weight"])
+            # every small tensor's first-step gradient and final value (BatchNorm, bias, stem, levels): tight per-tensor checks
+            for n, p in named:
+                if p.numel() <= 4096:
+                    out[k + "g0_all_" + n] = np.zeros(0, np.float32) if g0[n] is None else f32(g0[n])
+                    out[k + "final_all_" + n] = f32(p.detach().numpy())
+            out[k + "keys"] = np.array(list(model.state_dict().keys()))
+            out[k + "param_names"] = np.array([n for n, _ in named])
     out["steps"] = np.int64(steps); out["seed_model"] = np.int64(11)
     np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
 

@@ -108,6 +108,40 @@ def test_resume_from_reference_checkpoint_continues_its_curve(golden, fused):
 
 
 @pytest.mark.gpu
+def test_checkpoint_loaded_after_graph_capture_reaches_the_replayed_step(golden):
+    """A step object that has already captured its HIP graphs holds the addresses of the optimizer state; loading a
+    checkpoint afterwards must land in those very tensors.  One captured step on other data first, then the
+    reference's checkpoint, then one replay: loss, logits and step counter are the reference's next step."""
+    import quantized_cnn_amd.adp_qtz_fan as fan
+    from quantized_cnn_amd import checkpoint as ck
+    from quantized_cnn_amd.train import FusedTrainStep
+    g = golden("ckpt")
+    c = small_cfg()
+    model = fan.ResNet(c, 1).cuda().train()
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    fan.beta = int(g["beta"])
+    try:
+        step = FusedTrainStep(model, c, fan, use_graph=True)
+        step(torch.randn_like(x), y)  # captures and replays once: state tensors now belong to the graph
+        st0 = step.opts[0].state[step.ps[0]]
+        ptrs = (st0["exp_avg"].data_ptr(), st0["exp_avg_sq"].data_ptr(), st0["step"].data_ptr())
+        beta, _, _, _ = ck.load_checkpoint(CKPT, model, step.opts)
+        assert beta == int(g["beta"])
+        st1 = step.opts[0].state[step.ps[0]]
+        assert (st1["exp_avg"].data_ptr(), st1["exp_avg_sq"].data_ptr(), st1["step"].data_ptr()) == ptrs
+        assert float(st1["step"]) == 2
+        loss = float(step(x, y))
+    finally:
+        fan.beta = 1
+    assert abs(loss - float(g["loss_next"])) <= 2e-5 * float(g["loss_next"])
+    ref = g["logits_next"]
+    assert np.abs(step.logits.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert float(step.opts[0].state_dict()["state"][0]["step"]) == 3
+    sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
+    assert np.abs(sums - g["p_sum_after_next"]).max() <= 1e-3 * np.abs(g["p_sum_after_next"]).max()
+
+
+@pytest.mark.gpu
 def test_hard_mode_and_packed_export_match_reference_test_script(golden, tmp_path):
     """The reference's test-time model (adp_qtz_fan_test.py, hard assignment, eval mode) on the same
     checkpoint; then the packed export reproduces those logits without p_c."""

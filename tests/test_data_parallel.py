@@ -23,7 +23,7 @@ def _run(mode, out, world=2, extra=()):
                    HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "--mode", mode, "--out", out, *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=100)[0].decode() for p in procs]
+    logs = [p.communicate(timeout=150)[0].decode() for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
     return [torch.load("%s.rank%d.pt" % (out, r), weights_only=False) for r in range(world)]
@@ -83,3 +83,74 @@ def test_two_rank_training_equals_averaged_half_batches(tmp_path, graph):
         lr = 1e-3 if "q_level" in k else 1e-2
         bad = ((mine - v).abs() > 0.1 * steps * lr + 1e-5 * v.abs()).float().mean().item()
         assert bad <= 0.02 + 1.0 / v.numel(), (k, bad)
+
+
+def _full_batch_reference(bn_eval):
+    """Single process, whole batch of 8, the plain module path: model.forward + CrossEntropy + model_loss, autograd."""
+    import argparse
+    import quantized_cnn_amd.adp_qtz_hint as hint
+    c = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,
+                           prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+    hint.beta = 2
+    torch.manual_seed(7)
+    model = hint.ResNet(c, [0.1 * (i + 1) for i in range(20)], torch.zeros(10)).cuda().train()
+    if bn_eval:
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(8, 3, 32, 32, generator=g).cuda()
+    Y = torch.randint(0, 10, (8,), generator=g).cuda()
+    halves = [float(torch.nn.functional.cross_entropy(model.forward(X[i:i + 4]), Y[i:i + 4]).detach()) for i in (0, 4)] if bn_eval else None
+    logits = model.forward(X)
+    reg = hint.model_loss(c, hint.beta, model)
+    ce = torch.nn.functional.cross_entropy(logits, Y)
+    (ce + reg).backward()
+    hint.beta = 1
+    return float(ce), float(reg), halves, {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _assert_grads_equal_full_batch(r0, r1, ref_grads):
+    assert set(r0["grads"]) == set(ref_grads)
+    for n, want in ref_grads.items():
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n  # every rank holds the same averaged gradient
+        got = r0["grads"][n].double()
+        err = (got - want.double()).abs().max().item()
+        assert err <= 5e-5 * want.abs().max().item() + 1e-9, (n, err, want.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_frozen_batchnorm_equal_a_full_batch_autograd_step(tmp_path):
+    """An oracle that shares none of the exchange code: with BatchNorm on its running statistics the loss is a plain
+    mean over images, so two ranks with half batches (gradient scaled by 1/world in the loss kernel, summed by the
+    all-reduce, regulariser added once afterwards) must give the gradient of ONE autograd pass over the whole batch."""
+    r0, r1 = _run("gpu_eval", str(tmp_path / "ev"))
+    ce, reg, halves, grads = _full_batch_reference(bn_eval=True)
+    assert abs(r0["reg"] - reg) <= 1e-6 * reg and abs(r1["reg"] - reg) <= 1e-6 * reg
+    assert abs((r0["loss"] - r0["reg"]) - halves[0]) <= 1e-5 * halves[0]
+    assert abs((r1["loss"] - r1["reg"]) - halves[1]) <= 1e-5 * halves[1]
+    assert abs(0.5 * (halves[0] + halves[1]) - ce) <= 1e-6 * ce
+    _assert_grads_equal_full_batch(r0, r1, grads)
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_sync_batchnorm_equal_a_full_batch_step(tmp_path):
+    """DataParallel(sync_bn=True), eager step: the statistics span both ranks, so the job is the full-batch
+    training-mode step; and capturing such a step into a HIP graph is refused."""
+    r0, r1 = _run("gpu_syncbn", str(tmp_path / "sb"))
+    assert r0["graph_refused"] is True and r1["graph_refused"] is True
+    ce, reg, _, grads = _full_batch_reference(bn_eval=False)
+    assert abs(r0["reg"] - reg) <= 1e-6 * reg
+    assert abs(0.5 * ((r0["loss"] - r0["reg"]) + (r1["loss"] - r1["reg"])) - ce) <= 2e-5 * ce
+    _assert_grads_equal_full_batch(r0, r1, grads)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [0, 1])
+def test_exchange_path_on_rccl_single_rank(tmp_path, graph):
+    """Backend "nccl" (RCCL) with one rank: the step in its multi-GPU form (phase A graph, in-place all-reduce of
+    the flat gradient buffer on the device, phase B graph) gives the bits of the one-graph form."""
+    (r,) = _run("nccl1", str(tmp_path / "n1"), world=1, extra=("--steps", "4", "--graph", str(graph)))
+    assert r["backend"] == "nccl"
+    assert r["losses"] == r["losses_forced"], (r["losses"], r["losses_forced"])
+    assert r["equal"]

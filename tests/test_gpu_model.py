@@ -63,26 +63,68 @@ def close(a, b, rel):
 
 
 def adam_close(a, b, steps, lr):
-    """Parameters after `steps` Adam updates.  Adam moves every coordinate by about lr per step in the
-    direction of the gradient's sign, so a coordinate whose gradient is at rounding-noise level (or that
-    sits behind a ReLU decided by the last bit) can legitimately go the other way in another correct fp32
-    evaluation: up to 2*lr apart per such step.  (The `fix` fixture has such a ReLU element in its first
-    backward pass: with one summation order it lands on the reference's side and all parameters agree to
-    1e-5, with another it does not and 1-6 % of the coordinates end one step apart, the loss curve still
-    within 5e-5.)  Hence: no coordinate further apart than the 2*lr*steps bound, and at most 10 % of the
-    coordinates further apart than one step."""
+    """Parameters after `steps` Adam updates.  The first step is compared through its gradients (tight, below);
+    from the second step on the reference trajectory is no longer protected against a ReLU input that rounds to
+    the other side of zero in another correct fp32 evaluation, and Adam turns any gradient perturbation into a
+    displacement of a fraction of lr.  Measured on MI355X against the fixture: fan <= 5e-4*lr everywhere; fix and
+    hint up to 0.15*lr on p_c (0.5 % of the coordinates beyond 0.1*lr) and 0.65*lr on single BatchNorm biases.
+    Bound: nobody further than one step (lr) - five steps could carry 10*lr apart - and at most 2 % of the
+    coordinates further than 0.1*lr."""
     d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
-    return d.max() <= 2 * lr * steps * 1.01 and (d > lr).mean() <= 0.10
+    return d.max() <= lr and (d > 0.1 * lr).mean() <= 0.02 + 1.0 / d.size
 
 
 def grad_close(a, b, rel):
-    """Gradients through 19 ReLU layers: an activation within rounding distance of zero can fall on the
-    other side in another correct fp32 evaluation, which moves every upstream gradient by a discrete
-    amount (about 2e-3 of the tensor's scale at batch 8).  So: tight in the mean (relative L2 error <= rel)
-    or, when such a flip happened, within 5e-3 in L2 and 1e-2 of the scale pointwise."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
-    return close(a, b, rel) or (l2 <= 5e-3 and np.abs(a - b).max() <= 1e-2 * np.abs(b).max())
+    """First-step gradients: |a - b| <= rel * max|b|, no escape.  The fixture's batch was drawn so that no ReLU
+    input of the first forward pass lies within 3e-6 of zero (stored as <variant>_relu_margin), which is above
+    what summation order moves an activation by, so both sides see the same ReLU masks."""
+    return close(a, b, rel)
+
+
+def check_param_sums(model, g, k, steps=5):
+    """Per tensor: |sum(p) - sum(p_ref)| <= 2e-2 * numel * lr * steps + 1e-5 * |sum(p_ref)| (2 % of the distance
+    Adam can move the tensor's sum; measured <= 0.8 %)."""
+    for (n, p), want in zip(model.named_parameters(), g[k + "p_sum"]):
+        lr = 1e-3 if "q_level" in n else 1e-2
+        got = float(p.detach().double().sum())
+        assert abs(got - want) <= 2e-2 * p.numel() * lr * steps + 1e-5 * abs(want), (n, got, want)
+
+
+def check_small_tensors(model, g, k):
+    """Every tensor of up to 4096 elements (levels, BatchNorm, bias, stem) against the reference's final value, in
+    units of the tensor's learning rate: nobody further than one step, and over all of them together at most 5 %
+    of the coordinates further than 0.1 step (see adam_close for why not tighter)."""
+    ds = []
+    for n, p in model.named_parameters():
+        key = k + "final_all_" + n
+        if key in g.files:
+            lr = 1e-3 if "q_level" in n else 1e-2
+            d = np.abs(p.detach().cpu().numpy().astype(np.float64) - g[key]).reshape(-1) / lr
+            assert d.max() <= 1.0, (n, d.max())
+            ds.append(d)
+    assert len(ds) >= 50
+    d = np.concatenate(ds)
+    assert (d > 0.1).mean() <= 0.05, (d > 0.1).mean()
+
+
+def check_first_step_grads(named_grads, g, k, variant):
+    """named_grads: {name: gradient tensor or None}.  p_c by their first 4096 elements, the stem, the linear bias
+    and every level vector at 5e-5 of the tensor's largest entry; the BatchNorm gradients at 1e-4: they are sums over
+    N*H*W terms that cancel to 1e-3 of the terms' size (layer3 biases: entries of 1e-7), so the reference's own
+    rounding error is of that order on this scale (measured: <= 5.6e-5)."""
+    seen = 0
+    for n, gr in named_grads.items():
+        key = k + "g0_all_" + n
+        if key in g.files:
+            seen += 1
+            if g[key].size == 0:
+                assert gr is None and variant == "fix" and "q_level" in n, n
+            else:
+                assert grad_close(gr.cpu().numpy(), g[key], 1e-4 if ".bn" in n or n.startswith("bn") else 5e-5), (
+                    n, np.abs(gr.cpu().numpy() - g[key]).max() / np.abs(g[key]).max())
+    assert seen >= 50
+    for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
+        assert grad_close(named_grads[n + ".p_c"].reshape(-1)[:4096].cpu().numpy(), g[k + "dp0_head_" + n], 5e-5), n
 
 
 @pytest.mark.parametrize("variant", ["fan", "fix", "hint"])
@@ -118,6 +160,7 @@ def test_five_training_steps_match_reference(golden, variant, graph):
                     assert named[n + ".q_level"].grad is None and g[k + "dq0_" + n].size == 0
                 else:
                     assert grad_close(named[n + ".q_level"].grad.cpu().numpy(), g[k + "dq0_" + n], 5e-5), n
+            check_first_step_grads({n: p.grad for n, p in named.items()}, g, k, variant)
             for o in step.opts:
                 o.step()
             for o in step.opts:
@@ -134,8 +177,8 @@ def test_five_training_steps_match_reference(golden, variant, graph):
         # gradients can shift single coordinates by a step: compare at that resolution
         assert adam_close(named[n + ".p_c"].detach().reshape(-1)[:4096].cpu().numpy(), g[k + "p_final_head_" + n], 5, 1e-2), n
         assert adam_close(named[n + ".q_level"].detach().cpu().numpy(), g[k + "q_final_" + n], 5, 1e-3), n
-    sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
-    assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+    check_param_sums(model, g, k)
+    check_small_tensors(model, g, k)
 
 
 def test_hard_mode_forward_uses_codes(golden):
@@ -205,8 +248,8 @@ def test_fused_step_matches_reference_curve(golden, variant, graph, fuse_adam):
     assert abs(losses[0] - ref[0]) <= 2e-5 * ref[0], (losses, ref)
     assert np.abs(np.array(losses) - ref).max() <= 1e-4 * ref.max(), (losses, ref)
     assert np.abs(np.array(regs) - g[k + "reg"]).max() <= 1e-4 * g[k + "reg"].max()
-    sums = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
-    assert np.abs(sums - g[k + "p_sum"]).max() <= 1e-3 * np.abs(g[k + "p_sum"]).max()
+    check_param_sums(model, g, k)
+    check_small_tensors(model, g, k)
     named = dict(model.named_parameters())
     for n in ("layer1.0.conv1", "layer2.0.conv1", "layer3.2.conv2", "linear"):
         assert adam_close(named[n + ".p_c"].detach().reshape(-1)[:4096].cpu().numpy(), g[k + "p_final_head_" + n], 5, 1e-2), n
@@ -214,6 +257,79 @@ def test_fused_step_matches_reference_curve(golden, variant, graph, fuse_adam):
     sd = step.opts[0].state_dict()
     assert len(sd["state"]) == 19 and set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
     assert float(sd["state"][0]["step"]) == float(int(g["steps"]))
+
+
+@pytest.mark.parametrize("variant", ["fan", "fix", "hint"])
+def test_fused_step_first_gradients_match_reference(golden, variant):
+    """The fused step with its gradients kept (no Adam inside the synthesis-gradient kernel, no graph): after one
+    step every .grad holds what the reference's loss.backward() left, regulariser included."""
+    g = golden("train")
+    k = variant + "_"
+    assert float(g[k + "relu_margin"]) >= 3e-6
+    mod, c, model = build(variant, g)
+    model.train()
+    x, y = torch.from_numpy(g[k + "x"]).cuda(), torch.from_numpy(g[k + "y"]).cuda()
+    step = FusedTrainStep(model, c, mod, use_graph=False, fuse_adam=False)
+    loss = float(step(x, y))
+    assert abs(loss - g[k + "loss"][0]) <= 2e-5 * g[k + "loss"][0]
+    check_first_step_grads({n: p.grad for n, p in model.named_parameters()}, g, k, variant)
+
+
+@pytest.mark.parametrize("variant", ["fan", "fix", "hint"])
+@pytest.mark.parametrize("kind", ["plain", "fused_graph", "fused_graph_exact"])
+def test_batch_128_curves_match_reference(golden, variant, kind):
+    """The benchmark's batch.  Inputs are re-derived from the stored numpy seed (legacy RandomState stream).  First
+    logits and regulariser at 2e-5.  Loss curve: at this batch hundreds of ReLU inputs lie within rounding of zero
+    and Adam's first steps are sign-like, so two correct fp32 evaluations drift apart by about x30 per step (the
+    CPU restatement with F.conv2d instead of the nine-tap sum is 1.3e-4 off the reference at step 5 of the fan
+    case; this library 3.6e-5 in exact and 9e-4 in fast arithmetic, both equally close to a float64 evaluation
+    element by element).  Hence: steps 1-3 at 1e-4, steps 4-5 at 2e-3, and at 1e-4 throughout in exact arithmetic
+    for the two power-of-two variants."""
+    import quantized_cnn_amd.ops as ops
+    g = golden("train")
+    k = variant + "_b128_"
+    mod, c, model = build(variant, g)
+    model.train()
+    rx = np.random.RandomState(int(g[k + "xseed"]))
+    x = torch.from_numpy(rx.standard_normal((128, 3, 32, 32)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rx.randint(0, 10, 128).astype(np.int64)).cuda()
+    ops.EXACT_ARITHMETIC = kind.endswith("exact")
+    try:
+        step = TrainStep(model, c, mod) if kind == "plain" else FusedTrainStep(model, c, mod, use_graph=True)
+        losses = []
+        for it in range(5):
+            if it == 3:
+                mod.beta = 2
+            losses.append(float(step(x, y)))
+            if it == 0:
+                assert close(step.logits.cpu().numpy(), g[k + "logits0"], 2e-5)
+                if kind != "plain":
+                    assert abs(float(step.reg) - g[k + "reg"][0]) <= 2e-5 * g[k + "reg"][0]
+    finally:
+        mod.beta = 1
+        ops.EXACT_ARITHMETIC = False
+    rel = np.abs(np.array(losses) - g[k + "loss"]) / g[k + "loss"]
+    assert rel[:3].max() <= 1e-4 and rel.max() <= 2e-3, (losses, g[k + "loss"])
+    if kind.endswith("exact") and variant != "fan":
+        assert rel.max() <= 1e-4, (losses, g[k + "loss"])
+
+
+def test_second_step_object_on_one_model_keeps_the_stem_gradient(golden):
+    """Two FusedTrainStep objects on one model (a re-created step): each must receive conv0's weight gradient in
+    its own buffer."""
+    g = golden("train")
+    mod, c, model = build("fan", g)
+    model.train()
+    x, y = torch.from_numpy(g["fan_x"]).cuda(), torch.from_numpy(g["fan_y"]).cuda()
+    first = FusedTrainStep(model, c, mod, use_graph=False, fuse_adam=False)
+    second = FusedTrainStep(model, c, mod, use_graph=False, fuse_adam=False)  # built later, used later
+    first(x, y)
+    assert model.conv0.weight.grad.data_ptr() == first.stem_slot.data_ptr()
+    assert grad_close(model.conv0.weight.grad.cpu().numpy(), g["fan_g0_conv0"], 5e-5)
+    assert float(second.stem_slot.abs().max()) == 0.0  # untouched by the other object's step
+    second(x, y)
+    assert model.conv0.weight.grad.data_ptr() == second.stem_slot.data_ptr()
+    assert float(second.stem_slot.abs().max()) > 0.0
 
 
 def test_residual_blocks_match_reference_fixture(golden):
