@@ -131,9 +131,28 @@ __device__ __forceinline__ int find_segment(const SegTab &tab)
     return si;
 }
 
+// Order-preserving map of a float onto an unsigned integer (a < b  <=>  key(a) < key(b) for non-NaN values).
+__device__ __forceinline__ uint32_t float_key(float v)
+{
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 // EXACT: the bit-reproducible operation sequence (polynomial exp); otherwise exp on the
 // transcendental unit.  HARD (codes) implies EXACT at the call site.
-template <int G, int MEM, bool HARD, bool EXACT>
+// CODES_ONLY (with HARD; no W, no sum W^2 wanted): the code of a row is the arg-max of exp(beta * p / |p|), and
+// for beta > 0 that is the arg-max of p itself unless rounding merges the two largest values.  So the kernel
+// takes the arg-max of p with a group reduction and counts how many elements lie within a safety distance
+// of the maximum: x = beta * (p * rn) carries two roundings (<= 1.2e-7 * |beta| each side) and the polynomial
+// exp about 1.3e-7 relative, so elements whose x trails the maximum by at least 2e-6 + 1e-6 * |beta| are
+// strictly smaller after exp as well.  A row with a second element inside that distance (about one row in
+// 10^4 for uniform p), a non-finite or zero norm, or beta <= 0 goes through the exact sequence, so the codes are
+// those of the exact kernel bit for bit, at the cost of one compare-and-count per element instead of an exp.
+template <int G, int MEM, bool HARD, bool EXACT, bool CODES_ONLY = false>
 __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
 {
     constexpr int RPP = 64 / G;
@@ -186,7 +205,38 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
             const float my_rn = EXACT ? inv_norm(my_ss) : (beta * inv_norm(my_ss)) * LOG2E;
             float my_den = 1.0f, my_num = 0.0f;
             uint32_t my_bi = 0;
-            static_for<8>([&](auto U) {
+            bool slow = true;  // CODES_ONLY: some row of this batch needs the exact sequence (wavefront-uniform)
+            if constexpr (CODES_ONLY) {
+                // distance in p that corresponds to the safety distance in x: (2e-6 + 1e-6 * beta) / (beta * rn)
+                const float my_thr = (2e-6f / beta + 1e-6f) * __builtin_sqrtf(my_ss);
+                bool my_bad = !(my_ss > 0.0f && my_ss < __builtin_inff()) || !(beta > 0.0f);
+                static_for<8>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    const float thr = group_bcast<G, ub + u>(my_thr);
+                    float pv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[k] = (MEM != 0 || valid[k]) ? v[u][k] : -__builtin_inff();
+                    uint32_t bk = float_key(pv[0]), bi = 4 * j;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const uint32_t kk = float_key(pv[k]);
+                        const bool take = kk > bk;
+                        bk = take ? kk : bk;
+                        bi = take ? 4 * j + k : bi;
+                    }
+                    group_argmax<G>(bk, bi);
+                    const float pmax = key_float(bk);
+                    float cnt = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cnt += (pmax - pv[k] <= thr) ? 1.0f : 0.0f;
+                    cnt = group_sum<G>(cnt);
+                    const bool mine = (j == ub + u);
+                    my_bi = mine ? bi : my_bi;
+                    my_bad = mine ? (my_bad || !(cnt == 1.0f)) : my_bad;
+                });
+                slow = __builtin_amdgcn_ballot_w64(my_bad) != 0;
+            }
+            if (slow) static_for<8>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const float rn = group_bcast<G, ub + u>(my_rn);
                 float e[4];
@@ -218,7 +268,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
             const float w = my_num * (1.0f / my_den);
             const bool owner = (j >= ub) && (j < ub + 8);
             myW = owner ? w : myW;
-            if constexpr (HARD) myIdx = owner ? ((my_den == my_den) ? my_bi : 0u) : myIdx;
+            if constexpr (HARD) myIdx = owner ? ((my_den == my_den) ? my_bi : 0u) : myIdx;  // (fast path: my_den stays 1)
         });
         // lane (gq, j) now holds row j*RPP + gq of this iteration: one coalesced store each
         const long long rr = row0 + (long long)j * RPP + gq;
@@ -528,7 +578,7 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
 
 template <bool BWD>
 static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, const AdamArgs *adam,
-                         hipStream_t st)
+                         hipStream_t st, bool codes_only = false)
 {
     const AdamArgs ad = adam ? *adam : AdamArgs{};
 #define AQ_LAUNCH(GG, MM)                                                                                             \
@@ -537,7 +587,9 @@ static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &ta
         else if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
         else if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
         else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
-    } else if (hard)                                                                                                  \
+    } else if (hard && codes_only)                                                                                    \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); \
+    else if (hard)                                                                                                    \
         hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
     else if (exact)                                                                                                   \
         hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);      \
@@ -601,12 +653,14 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             tab.nseg = 0;
             tab.K = pl.K;
             int nblocks = 0;
-            bool hard = false;
+            bool hard = false, wants_w = false;  // wants_w: some layer of the launch asks for W or sum W^2
             auto flush = [&]() {
-                if (tab.nseg) launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st);
+                if (tab.nseg)
+                    launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st,
+                                      hard && !wants_w);
                 tab.nseg = 0;
                 nblocks = 0;
-                hard = false;
+                hard = wants_w = false;
             };
             for (int i = 0; i < nseg; ++i) {
                 const aq_seg &s = segs[i];
@@ -629,6 +683,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                     if (al) d.rag = stream_policy ? 2 : 1;
                 }
                 hard = hard || s.idx != nullptr || s.W_hard != nullptr;
+                wants_w = wants_w || s.W != nullptr || d.part != nullptr;
                 const long long nb = (wave_tiles(s.rows, pl.K) + WAVES - 1) / WAVES;
                 AQ_REQUIRE(nb + nblocks < (1LL << 31), -E2BIG, "segment %d: too many rows for one launch", i);
                 nblocks += (int)nb;

@@ -57,6 +57,10 @@ def test_synth_forward_bit_exact(L, rows):
     assert_bits_equal(out["W_hard"][0].cpu().numpy(), ref["W_hard"], "W_hard")
     ss = float(out["sumsq"].cpu()[0])
     assert abs(ss - ref["sumsq"]) <= 2e-5 * ref["sumsq"] + 1e-30
+    # codes alone (what a hard-mode forward pass asks for): the arg-max-of-p kernel, same codes bit for bit
+    out4 = ops.synth_forward([cu(p)], [cu(q)], beta, soft=False, codes=True)
+    assert np.array_equal(out4["idx"][0].cpu().numpy().astype(np.int32), ref["idx"])
+    assert_bits_equal(out4["W_hard"][0].cpu().numpy(), ref["W_hard"], "W_hard(codes only)")
     # soft-only launch with the exact flag gives the same bits
     out2 = ops.synth_forward([cu(p)], [cu(q)], beta, soft=True, codes=False, sumsq=False, exact=True)
     assert_bits_equal(out2["W"][0].cpu().numpy(), ref["W"], "W(soft only)")
@@ -83,6 +87,8 @@ def test_synth_forward_reference_fixtures(golden):
         assert np.array_equal(idx.astype(np.int32), ref["idx"])
         flag = g[k + "rounding_tie"]
         assert np.all((idx == g[k + "idx"]) | flag)
+        only = ops.synth_forward([cu(p)], [cu(q)], beta, soft=False, codes=True)
+        assert np.array_equal(only["idx"][0].cpu().numpy(), idx), c  # special rows included: ties, zeros, huge, tiny
         ok = ~np.isnan(g[k + "W"])
         assert np.all(np.abs(W[ok] - g[k + "W"][ok]) <= 1e-6 * np.abs(q).max() + 2e-6 * np.abs(g[k + "W"][ok]))
         assert np.array_equal(np.isnan(W), np.isnan(g[k + "W"]))
@@ -113,6 +119,37 @@ def test_synth_backward_bit_exact_dp(L, rows):
     tol = 3e-5 * np.abs(dp_ref).max(axis=1, keepdims=True) + 1e-6 * np.abs(dp_ref).max()
     assert np.all(np.abs(got - dp_ref) <= tol)
     assert np.abs(dq[0].cpu().numpy() - dq_ref).max() <= 2e-5 * np.abs(dq_ref).max() + 1e-12
+
+
+@pytest.mark.parametrize("L", [31, 32, 64, 100])
+@pytest.mark.parametrize("beta", [1.0, 4.0, 64.0, 0.03, -2.0, 0.0])
+def test_codes_only_kernel_on_near_ties(L, beta):
+    """Rows built to sit on the decision boundary of the codes-only kernel: the two (or three) largest
+    coefficients 0 to 40 ulps apart, in either index order, scattered over the lanes; some rows with an exact
+    tie, a NaN, an infinity or all zeros.  Codes must be those of the exact sequence (= the oracle's)."""
+    rs = np.random.RandomState(int(L * 31 + (beta + 70) * 1000))
+    rows = 6000
+    p = rs.random_sample((rows, L)).astype(np.float32) * 0.9
+    for r in range(rows):
+        i, j, k = rs.choice(L, 3, replace=False)
+        top = np.float32(0.95 + 0.04 * rs.random_sample())
+        p[r, i] = top
+        p[r, j] = (top.view(np.uint32) - np.uint32(rs.randint(0, 41))).view(np.float32)
+        if r % 3 == 0:
+            p[r, k] = (top.view(np.uint32) - np.uint32(rs.randint(0, 9))).view(np.float32)
+        if r % 7 == 0:
+            p[r] = -p[r]  # all-negative rows: the maximum is the element closest to zero
+    p[11] = 0.0
+    p[12, 3] = np.nan
+    p[13, 5] = np.inf
+    p[14] = 1e-25
+    p[15] = 3e19
+    q = rand_levels(rs, L)
+    ref = O.synth_fwd(p, q, beta)
+    out = ops.synth_forward([cu(p)], [cu(q)], beta, soft=False, codes=True)
+    got = out["idx"][0].cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, ref["idx"]), np.argwhere(got != ref["idx"])[:5]
+    assert_bits_equal(out["W_hard"][0].cpu().numpy(), ref["W_hard"], "W_hard")
 
 
 def test_synth_multi_segment_resnet20_shapes():

@@ -56,6 +56,8 @@ def test_streaming_forward_vs_oracle(L):
     assert np.array_equal(hard["idx"][0].cpu().numpy().astype(np.int32), ref["idx"])
     assert bits_equal(hard["W_hard"][0].cpu().numpy(), ref["W_hard"])
     assert abs(float(hard["sumsq"][0]) - ref["sumsq"]) <= 2e-5 * ref["sumsq"]
+    only = ops.synth_forward([pd], [qd], beta, soft=False, codes=True)  # codes alone: the arg-max-of-p instantiation
+    assert torch.equal(only["idx"][0], hard["idx"][0]) and torch.equal(only["W_hard"][0], hard["W_hard"][0])
     soft = ops.synth_forward([pd], [qd], beta, soft=True, sumsq=True, exact=True)
     assert bits_equal(soft["W"][0].cpu().numpy(), ref["W"])
     assert torch.equal(soft["sumsq"], hard["sumsq"])
@@ -138,6 +140,9 @@ def test_one_billion_coefficients_properties(L):
     assert torch.equal(hard["W"][0], again["W"][0]) and torch.equal(hard["idx"][0], again["idx"][0])
     assert torch.equal(hard["sumsq"], again["sumsq"])
     del again
+    only = ops.synth_forward([p], [qd], beta, soft=False, codes=True)
+    assert torch.equal(only["idx"][0], hard["idx"][0]) and torch.equal(only["W_hard"][0], hard["W_hard"][0])
+    del only
     fast = ops.synth_forward([p], [qd], beta, soft=True, sumsq=True, exact=False)
     assert bool(torch.isfinite(fast["W"][0]).all())
     assert float((fast["W"][0] - hard["W"][0]).abs().max()) <= 4e-6 * float(np.abs(q).max())
