@@ -103,6 +103,9 @@ struct ConvArgs {
     const float *bx, *bgamma, *bbeta, *bmean, *brstd;
     float2 *bwd_part;
     int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
+    // general kernel (conv_gemm_chunked_kernel) only: kernel size, taps per channel, rows / columns of padding in
+    // front of the (dilated) input, channels per LDS chunk, k extent of a chunk padded to whole k-blocks
+    int ks, ks2, padT, CK, Kc;
 };
 
 // Fill the LDS image xs[nch][plane] of one input tile: plane = rows_in x pitch elements starting at
@@ -302,6 +305,183 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
     }
 
     // ---- epilogue: D[row = 4*(lane>>4)+r][col = lane&15] -----------------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (oyx[nt] < 0) continue;
+            const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = m0 + 16 * m + 4 * kq + r;
+                if (ch < a.M) {
+                    const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
+                    a.out[o] = a.res ? acc[m][nt][r] + a.res[o] : acc[m][nt][r];
+                }
+            }
+        }
+}
+
+// General form of the forward / dgrad GEMM: any odd kernel size up to 7, any padding below it, stride 1 | 2, any
+// number of channels.  Same tile geometry and fragment scheme as conv_gemm_kernel, but the input channels pass
+// through LDS in chunks of CK (a multiple of 16 unless the tensor has fewer), the accumulators staying in
+// registers across chunks; k inside a chunk is (channel, tap) like everywhere else, so a chunk's k range is a
+// contiguous run of the weight matrix' k axis.  MT up to 8 (128 output channels per workgroup): with hundreds of
+// channels the 16x16x4 tiles are finally fed from one staged image for many MFMAs.
+template <int MT, int NT, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *ktab = reinterpret_cast<int *>(smem);            // [Kc] LDS offset of k inside a chunk
+    int *atab = ktab + a.Kc;                              // [Kc] weight offset of k inside a chunk (dgrad only)
+    float *qs = reinterpret_cast<float *>(atab + (MODE == MODE_DGRAD ? a.Kc : 0));   // [L] levels (codes only)
+    float *xs = qs + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) : 0);                // [CK][rows_in][pitch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jn = lane & 15, kq = lane >> 4;
+
+    int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int m0 = blockIdx.y * 16 * MT;
+    const int ks = a.ks, ks2 = a.ks2;
+
+    for (int k = tid; k < a.Kc; k += 256) {
+        int off = 0, aoff = 0;
+        if (k < a.CK * ks2) {
+            const int c = k / ks2, tap = k - ks2 * c;
+            const int ty_ = tap / ks, tx_ = tap - ks * ty_;
+            off = c * a.plane + ty_ * a.pitch + tx_;
+            aoff = c * a.Cin * ks2 + (ks2 - 1 - tap);  // W[c0 + c (= co), ., flipped tap]
+        }
+        ktab[k] = off;
+        if (MODE == MODE_DGRAD) atab[k] = aoff;
+    }
+    if (MODE == MODE_FWD_CODES)
+        for (int i = tid; i < a.L; i += 256) qs[i] = a.q[i];
+
+    int pixbase[NT];
+    int oyx[NT];  // (oy << 16) | ox, or -1 when outside the output
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int pr = (wave * NT + t) * 16 + jn;
+        const int py = pr / a.TW, px = pr - py * a.TW;
+        pixbase[t] = py * a.rs * a.pitch + px * a.rs;
+        const int oy = oy0 + py, ox = ox0 + px;
+        oyx[t] = (oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
+    }
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int r0 = oy0 * a.rs - a.padT, c0 = ox0 * a.rs - a.padT;
+    const long long chs = (long long)a.IH * a.IW;
+    const float *img = a.in + (long long)n * a.KC * chs;
+    const int nkb = a.Kc >> 4;
+
+    for (int cbase = 0; cbase < a.KC; cbase += a.CK) {
+        const int nvalid = min(a.CK, a.KC - cbase);
+        const int kvalid = nvalid * ks2;       // k of this chunk that carry weights
+        const int kg0 = cbase * ks2;           // first global k of the chunk
+        if (cbase) __syncthreads();            // every wavefront is done reading the previous chunk's image
+        // LDS image of the chunk: rows_in x pitch per channel from (r0, c0) in (dilated) input coordinates, zero
+        // outside the tensor and for channels beyond the tensor's
+        for (int e = tid; e < a.plane; e += 256) {
+            const int r = e / a.pitch, cc = e - r * a.pitch;
+            int gy = r0 + r, gx = c0 + cc;
+            bool ok = gy >= 0 && gx >= 0;
+            if (a.dil == 2) {
+                ok = ok && !((gy | gx) & 1);
+                gy >>= 1;
+                gx >>= 1;
+            }
+            ok = ok && gy < a.IH && gx < a.IW;
+            const float *src = img + (long long)cbase * chs + (ok ? gy * a.IW + gx : 0);
+            for (int c = 0; c < a.CK; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (ok && c + u < nvalid) ? src[(long long)(c + u) * chs] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + u < a.CK) xs[(c + u) * a.plane + e] = v[u];
+            }
+        }
+        __syncthreads();
+
+        auto load_a = [&](int kb, float (&av)[MT][4]) {
+            const int kbase = 16 * kb + 4 * kq;  // inside the chunk
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = m0 + 16 * m + jn;
+                const bool rok = row < a.M;
+                if (MODE == MODE_DGRAD) {
+                    const int4 ao = *reinterpret_cast<const int4 *>(&atab[kbase]);
+                    const int aof[4] = {ao.x, ao.y, ao.z, ao.w};
+                    const float *wb = a.W + (long long)cbase * a.Cin * ks2 + (long long)row * ks2;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) av[m][t] = (rok && kbase + t < kvalid) ? wb[aof[t]] : 0.0f;
+                } else if (MODE == MODE_FWD_CODES) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        av[m][t] = (rok && kbase + t < kvalid) ? qs[a.idx[(long long)row * a.K + kg0 + kbase + t]] : 0.0f;
+                } else {
+                    if (a.vecA && kbase + 3 < kvalid) {
+                        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (rok) w4 = *reinterpret_cast<const float4 *>(&a.W[(long long)row * a.K + kg0 + kbase]);
+                        av[m][0] = w4.x; av[m][1] = w4.y; av[m][2] = w4.z; av[m][3] = w4.w;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) av[m][t] = (rok && kbase + t < kvalid) ? a.W[(long long)row * a.K + kg0 + kbase + t] : 0.0f;
+                    }
+                }
+            }
+        };
+        auto load_k = [&](int kb, int (&kof)[4]) {
+            const int4 ko = *reinterpret_cast<const int4 *>(&ktab[16 * (kb < nkb ? kb : nkb - 1) + 4 * kq]);
+            kof[0] = ko.x; kof[1] = ko.y; kof[2] = ko.z; kof[3] = ko.w;
+        };
+        auto load_b = [&](const int (&kof)[4], float (&bv)[4][NT]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xs[pixbase[nt] + kof[t]];
+        };
+        float av[MT][4], an[MT][4], bv[4][NT], bn[4][NT];
+        int kof1[4], kof2[4];
+        const int nkb_run = (kvalid + 15) >> 4;  // k-blocks of the chunk that hold any weight
+        load_a(0, av);
+        load_k(0, kof1);
+        load_b(kof1, bv);
+        load_k(1, kof1);
+        for (int kb = 0; kb < nkb_run; ++kb) {
+            if (kb + 1 < nkb_run) {
+                load_a(kb + 1, an);
+                load_b(kof1, bn);
+            }
+            load_k(kb + 2, kof2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][t], bv[t][nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                kof1[t] = kof2[t];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m][t] = an[m][t];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[t][nt] = bn[t][nt];
+            }
+        }
+    }
+
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -779,7 +959,8 @@ struct WgradArgs {
     // when bn_mean is set, x is a raw tensor and the operand is relu(batch_norm(x)) with these statistics
     const float *bn_gamma, *bn_beta, *bn_mean, *bn_rstd;
     int N, Cin, H, Wd, Cout, stride, Ho, Wo;
-    int K9;                      // Cin*9
+    int ks, ks2, pad;            // kernel size, taps per channel, padding (3, 9, 1 for the reference's layers)
+    int K9;                      // Cin*ks2: columns (ci, tap) of the weight-gradient matrix
     int TW, TH, tiles_x, tiles_y;
     int pitch, rows_in, plane;   // LDS image of x
     int cpitch;                  // LDS pitch of a dy channel (TH*TW + 2)
@@ -816,7 +997,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int m0 = bc.y * 16 * MG;   // first output channel of this group
     const int j0 = bc.z * 16 * NG;   // first (ci, tap) column of this group
-    const int c_lo = j0 / 9;               // first input channel those columns touch
+    const int c_lo = a.ks2 == 9 ? j0 / 9 : j0 / a.ks2;  // first input channel those columns touch
     const int ceff = min(a.Cin - c_lo, a.CW);  // channels staged by this workgroup
 
     // compute wavefronts: column (ci, tap) owned by this lane in each n-tile -> offset inside the x image
@@ -826,8 +1007,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
         const int jcol = j0 + 16 * g + jn;
         int off = 0;
         if (jcol < a.K9) {
-            const int ci = jcol / 9, tap = jcol - 9 * ci;
-            off = (ci - c_lo) * a.plane + (tap / 3) * a.pitch + (tap % 3);
+            if (a.ks2 == 9) {  // (divisions by constants)
+                const int ci = jcol / 9, tap = jcol - 9 * ci;
+                off = (ci - c_lo) * a.plane + (tap / 3) * a.pitch + (tap % 3);
+            } else {
+                const int ci = jcol / a.ks2, tap = jcol - a.ks2 * ci;
+                off = (ci - c_lo) * a.plane + (tap / a.ks) * a.pitch + (tap % a.ks);
+            }
         }
         joff[g] = off;
     }
@@ -846,7 +1032,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[m][g] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int r0 = oy0 * a.stride - 1, c0 = ox0 * a.stride - 1;
+    const int r0 = oy0 * a.stride - a.pad, c0 = ox0 * a.stride - a.pad;
     const int nblk16 = npix >> 4;
     int nch = a.N - ig * a.IPB;
     nch = nch < a.IPB ? nch : a.IPB;  // chunks (images) of this workgroup
@@ -1261,14 +1447,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJo
 
 // ------------------------------------------------------------------------------------- host side
 
+// 3x3 / padding 1 is the reference's only configuration (adp_qtz_fan.py:574-601 is written for any ksize / stride /
+// padding) and has the tuned kernels; other odd sizes up to 7x7 and any padding below the kernel size run on the
+// general kernels.
 static int check_conv(const char *who, int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad)
 {
-    AQ_REQUIRE(ks == 3 && pad == 1, -ENOTSUP, "%s: only 3x3 kernels with padding 1 are implemented (got k=%d pad=%d)", who, ks, pad);
+    AQ_REQUIRE(ks >= 1 && ks <= 7 && (ks & 1) && pad >= 0 && pad < ks, -ENOTSUP,
+               "%s: kernels of 1x1, 3x3, 5x5, 7x7 with padding below the kernel size are implemented (got k=%d pad=%d)", who, ks, pad);
     AQ_REQUIRE(stride == 1 || stride == 2, -ENOTSUP, "%s: stride must be 1 or 2 (got %d)", who, stride);
     AQ_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && Wd >= 1, -EINVAL, "%s: bad sizes", who);
-    AQ_REQUIRE(H < 32768 && Wd < 32768 && (long long)Cin * 9 < (1 << 20) && (long long)Cout * 9 < (1 << 20), -E2BIG, "%s: dimension too large", who);
+    AQ_REQUIRE(H + 2 * pad >= ks && Wd + 2 * pad >= ks, -EINVAL, "%s: input %dx%d smaller than the kernel", who, H, Wd);
+    AQ_REQUIRE(H < 32768 && Wd < 32768 && (long long)Cin * ks * ks < (1 << 20) && (long long)Cout * ks * ks < (1 << 20), -E2BIG,
+               "%s: dimension too large", who);
     return 0;
 }
+static inline int conv_out(int H, int ks, int stride, int pad) { return (H + 2 * pad - ks) / stride + 1; }
 
 static void pick_tile(int OW, int npix, int &TW, int &TH)
 {
@@ -1286,6 +1479,66 @@ struct ConvStatsPlan {
     size_t lds;
 };
 constexpr int CONV_STATS_MAX_PARTS = 512;  // the consumer keeps ceil(P / 64) partials per lane in registers
+
+// The general kernel: any kernel size / padding / channel count (see conv_gemm_chunked_kernel).
+template <int MODE>
+static int launch_chunked(ConvArgs &a, int N, hipStream_t st, const char *who)
+{
+    const int mtiles = (a.M + 15) / 16;
+    int MT = mtiles >= 8 ? 8 : (mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1)), NT = 2;
+    a.par = 0; a.halo = a.padT;
+    auto blocks = [&](int mt, int nt) {
+        int TW, TH;
+        pick_tile(a.OW, 64 * nt, TW, TH);
+        return (long long)N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW) * ((mtiles + mt - 1) / mt);
+    };
+    while (blocks(MT, NT) < 512 && (NT > 1 || MT > 1)) {
+        if (MT > 4) MT >>= 1;
+        else if (NT > 1) NT = 1;
+        else MT >>= 1;
+    }
+    if (NT > 1) {
+        int tw, th;
+        pick_tile(a.OW, 128, tw, th);
+        if (th > a.OH) NT = 1;
+    }
+    pick_tile(a.OW, 64 * NT, a.TW, a.TH);
+    a.tiles_x = (a.OW + a.TW - 1) / a.TW;
+    a.tiles_y = (a.OH + a.TH - 1) / a.TH;
+    a.pitch = (a.TW - 1) * a.rs + a.ks;
+    a.rows_in = (a.TH - 1) * a.rs + a.ks;
+    a.plane = a.rows_in * a.pitch;
+    // channels per chunk: about 144 k per chunk (nine k-blocks between two barriers), within 48 KiB of LDS
+    int CK = a.KC;
+    if (a.KC >= 16) {
+        const int want = std::max(16, ((144 / a.ks2) + 15) & ~15);
+        const int fit = (int)((48 * 1024) / ((size_t)a.plane * 4)) & ~15;
+        CK = std::max(16, std::min(want, fit));
+        CK = std::min(CK, (a.KC + 15) & ~15);
+    }
+    a.CK = CK;
+    a.Kc = (CK * a.ks2 + 15) & ~15;
+    a.Kpad = a.Kc;
+    a.vecA = (a.K % 4 == 0) && (((uintptr_t)a.W & 15) == 0) && ((CK * a.ks2) % 4 == 0);
+    const size_t lds = (size_t)a.Kc * 4 * (MODE == MODE_DGRAD ? 2 : 1) + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) * 4 : 0) + (size_t)CK * a.plane * 4;
+    AQ_REQUIRE(lds <= 64 * 1024, -E2BIG, "%s: input tile needs %zu bytes of LDS (limit 65536)", who, lds);
+    const long long gx = (long long)N * a.tiles_x * a.tiles_y;
+    AQ_REQUIRE(gx < (1LL << 31), -E2BIG, "%s: grid too large", who);
+    const unsigned gy = (unsigned)((mtiles + MT - 1) / MT);
+    AQ_REQUIRE(gy < 65536, -E2BIG, "%s: too many output channels", who);
+    dim3 grid((unsigned)gx, gy);
+#define AQ_CH(MM, NN) hipLaunchKernelGGL((conv_gemm_chunked_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
+    if (MT == 8 && NT == 2) AQ_CH(8, 2);
+    else if (MT == 8) AQ_CH(8, 1);
+    else if (MT == 4 && NT == 2) AQ_CH(4, 2);
+    else if (MT == 4) AQ_CH(4, 1);
+    else if (MT == 2 && NT == 2) AQ_CH(2, 2);
+    else if (MT == 2) AQ_CH(2, 1);
+    else if (NT == 2) AQ_CH(1, 2);
+    else AQ_CH(1, 1);
+#undef AQ_CH
+    return check_launch(who);
+}
 
 // dry: no launch; returns 1 when the persistent kernel (the one that can normalise its input) would run
 // par: stride-2 dgrad by output parity classes (persistent kernel only); *fell = true when that kernel does not
@@ -1333,7 +1586,6 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
 #endif
     size_t lds = (size_t)a.Kpad * 4 * (MODE == MODE_DGRAD ? 2 : 1) + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) * 4 : 0) +
                  (size_t)a.KC * a.plane * 4;
-    AQ_REQUIRE(lds <= 64 * 1024, -E2BIG, "%s: input tile needs %zu bytes of LDS (limit 65536): too many channels", who, lds);
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     AQ_REQUIRE(gx < (1LL << 31), -E2BIG, "%s: grid too large", who);
     const unsigned gy = (unsigned)((mtiles + MT - 1) / MT);
@@ -1397,6 +1649,7 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
     AQ_REQUIRE(!a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
+    if (lds > 64 * 1024) return launch_chunked<MODE>(a, N, st, who);  // too many channels for one LDS image: chunks
     dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
     if (MT == 4 && NT == 2) AQ_GEMM(4, 2);
@@ -1412,6 +1665,12 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
 template <int MODE>
 static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool dry = false, ConvStatsPlan *plan = nullptr)
 {
+    if (a.ks != 3 || a.padT != 1) {  // anything but 3x3 / padding 1: the general kernel (no epilogues)
+        if (plan) *plan = ConvStatsPlan{};
+        if (dry) return 0;
+        AQ_REQUIRE(!a.bn_on && !a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no fused normalisation / statistics epilogue for this kernel size", who);
+        return launch_chunked<MODE>(a, N, st, who);
+    }
     // stride-2 dgrad: by parity classes when the class shares of the k axis are whole pairs of k-blocks
     if (MODE == MODE_DGRAD && a.dil == 2 && a.KC % 32 == 0 && !(a.OH & 1) && !(a.OW & 1) && a.IH * 2 == a.OH && a.IW * 2 == a.OW) {
         ConvArgs b = a;
@@ -1425,11 +1684,12 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
     return launch_gemm_impl<MODE>(a, N, st, who, dry, plan, false, nullptr);
 }
 
-static void conv_fwd_args(ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride)
+static void conv_fwd_args(ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride, int ks = 3, int pad = 1)
 {
     a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
-    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.ks = ks; a.ks2 = ks * ks; a.padT = pad;
+    a.M = Cout; a.KC = Cin; a.K = Cin * ks * ks;
+    a.OH = conv_out(H, ks, stride, pad); a.OW = conv_out(Wd, ks, stride, pad);
     a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
 }
 
@@ -1443,7 +1703,7 @@ static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, c
     ConvArgs a = {};
     a.in = x; a.W = W; a.idx = idx; a.q = q; a.L = L; a.out = y; a.res = res;
     a.stat_part = stat_part;
-    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride, ks, pad);
     return idx ? launch_gemm<MODE_FWD_CODES>(a, N, st, who, false, plan) : launch_gemm<MODE_FWD>(a, N, st, who, false, plan);
 }
 
@@ -1476,7 +1736,7 @@ size_t aq_conv_stats_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, i
     using namespace aq;
     if (check_conv("aq_conv_stats_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     ConvArgs a = {};
-    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride, ksize, pad);
     ConvStatsPlan plan;
     launch_gemm<MODE_FWD>(a, N, nullptr, "aq_conv_stats_bytes", true, &plan);
     return (size_t)plan.P * Cout * sizeof(float2);
@@ -1508,12 +1768,13 @@ int aq_conv_fwd_codes(const float *x, const uint8_t *idx, const float *q, int L,
     return aq::conv_fwd_common(x, nullptr, idx, q, L, nullptr, y, N, Cin, H, Wd, Cout, ksize, stride, pad, static_cast<hipStream_t>(stream), "aq_conv_fwd_codes");
 }
 
-static void conv_dgrad_args(aq::ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride)
+static void conv_dgrad_args(aq::ConvArgs &a, int N, int Cin, int H, int Wd, int Cout, int stride, int ks = 3, int pad = 1)
 {
     a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cin; a.KC = Cout; a.K = Cout * 9;
+    a.ks = ks; a.ks2 = ks * ks; a.padT = ks - 1 - pad;  // dx = full correlation of the (dilated) dy with the flipped kernel
+    a.M = Cin; a.KC = Cout; a.K = Cout * ks * ks;
     a.OH = H; a.OW = Wd;
-    a.IH = (H + 2 - 3) / stride + 1; a.IW = (Wd + 2 - 3) / stride + 1;
+    a.IH = aq::conv_out(H, ks, stride, pad); a.IW = aq::conv_out(Wd, ks, stride, pad);
     a.rs = 1; a.dil = stride;
 }
 
@@ -1526,7 +1787,7 @@ static int conv_dgrad_common(const char *who, const float *dy, const float *W, c
     AQ_REQUIRE(dy && W && dx, -EFAULT, "%s: NULL pointer", who);
     ConvArgs a = {};
     a.in = dy; a.W = W; a.out = dx; a.res = res;
-    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride, ksize, pad);
     return launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), who);
 }
 
@@ -1547,7 +1808,7 @@ size_t aq_conv_dgrad_bn_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize
     using namespace aq;
     if (check_conv("aq_conv_dgrad_bn_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     ConvArgs a = {};
-    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride, ksize, pad);
     ConvStatsPlan plan;
     launch_gemm<MODE_DGRAD>(a, N, nullptr, "aq_conv_dgrad_bn_bytes", true, &plan);
     return (size_t)plan.P * Cin * sizeof(float2);
@@ -1570,7 +1831,7 @@ int aq_conv_dgrad_bn(const float *dy, const float *W, float *dz, int N, int Cin,
     a.in = dy; a.W = W; a.out = dz;
     a.bx = x; a.bgamma = gamma; a.bbeta = beta; a.bmean = save_mean; a.brstd = save_rstd;
     a.bwd_part = static_cast<float2 *>(sums);
-    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride, ksize, pad);
     ConvStatsPlan plan;
     if (int rc = launch_gemm<MODE_DGRAD>(a, N, static_cast<hipStream_t>(stream), "aq_conv_dgrad_bn", false, &plan)) return rc;
     *desc = aq_conv_stats{plan.P, plan.ntiles, plan.tile_px};
@@ -1620,35 +1881,57 @@ static void wgrad_pad(int stride, int K9, int rows_in, int &pitch, int &plane)
     plane = bpl;
 }
 
+static int wgrad_plan_with(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &lds, size_t &ws_bytes, int ng_cap, int npix_cap);
+
+// Plan of the slab kernel.  The preferred tile group (as many (ci, tap) columns per workgroup as the registers hold)
+// may need more LDS than a CU has once many input channels, a large kernel or stride 2 widen the staged image:
+// then fewer columns per workgroup (fewer input channels staged), then smaller pixel tiles.
 static int wgrad_plan(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &lds, size_t &ws_bytes)
 {
+    const int caps[4][2] = {{18, 128}, {9, 128}, {3, 128}, {3, 64}};
+    int rc = 0;
+    for (int i = 0; i < 4; ++i) {
+        aq::WgradArgs t = a;
+        rc = wgrad_plan_with(t, MG, NG, grid, lds, ws_bytes, caps[i][0], caps[i][1]);
+        if (rc != -E2BIG || i == 3) {
+            a = t;
+            return rc;
+        }
+    }
+    return rc;
+}
+
+static int wgrad_plan_with(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &lds, size_t &ws_bytes, int ng_cap, int npix_cap)
+{
     using namespace aq;
-    a.Ho = (a.H + 2 - 3) / a.stride + 1;
-    a.Wo = (a.Wd + 2 - 3) / a.stride + 1;
-    a.K9 = a.Cin * 9;
+    if (a.ks == 0) { a.ks = 3; a.pad = 1; }
+    a.ks2 = a.ks * a.ks;
+    a.Ho = conv_out(a.H, a.ks, a.stride, a.pad);
+    a.Wo = conv_out(a.Wd, a.ks, a.stride, a.pad);
+    a.K9 = a.Cin * a.ks2;
     const int mtiles = (a.Cout + 15) / 16, ntiles = (a.K9 + 15) / 16;
     // tile group kept in registers by every compute wavefront: MG x NG <= 18 tiles (72 accumulator
     // registers + two operand sets fit the 256-register budget of an 8-wavefront workgroup)
-    if (ntiles <= 3) NG = 3;
-    else if (ntiles <= 9) NG = 9;
+    if (ntiles <= 3 || ng_cap <= 3) NG = 3;
+    else if (ntiles <= 9 || ng_cap <= 9) NG = 9;
     else NG = 18;
     MG = (NG == 9 && mtiles >= 2) ? 2 : 1;
-    pick_tile(a.Wo, 128, a.TW, a.TH);
+    pick_tile(a.Wo, npix_cap, a.TW, a.TH);
     if ((long long)a.Ho * a.Wo <= 64) pick_tile(a.Wo, 64, a.TW, a.TH);
     a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
     a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
-    a.pitch = (a.TW - 1) * a.stride + 3;
-    a.rows_in = (a.TH - 1) * a.stride + 3;
+    a.pitch = (a.TW - 1) * a.stride + a.ks;
+    a.rows_in = (a.TH - 1) * a.stride + a.ks;
     a.plane = a.rows_in * a.pitch;
     {   // channels touched by the 16*NG consecutive (ci, tap) columns of one workgroup
         const int gzs = (ntiles + NG - 1) / NG;
         a.CW = 1;
         for (int z = 0; z < gzs; ++z) {
             const int j0 = z * 16 * NG, j1 = std::min(a.K9, j0 + 16 * NG) - 1;
-            a.CW = std::max(a.CW, j1 / 9 - j0 / 9 + 1);
+            a.CW = std::max(a.CW, j1 / a.ks2 - j0 / a.ks2 + 1);
         }
     }
-    {   // pad the LDS image against bank conflicts when that keeps the per-lane element count (the kernel
+    if (a.ks == 3) {  // pad the LDS image against bank conflicts when that keeps the per-lane element count (the kernel
         // variants are instantiated per count) and the LDS budget
         int pp = a.pitch, pl = a.plane;
         wgrad_pad(a.stride, a.K9, a.rows_in, pp, pl);
@@ -1681,7 +1964,7 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
 {
     if (aq::check_conv("aq_conv_wgrad_workspace_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     aq::WgradArgs a = {};
-    a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride;
+    a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ksize; a.pad = pad;
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
@@ -1695,7 +1978,7 @@ static int wgrad_variant(const aq::WgradArgs &a, int MG, int NG)
 {
     const int c4 = (a.CW + 3) / 4, jx = (a.plane + 63) / 64;
     const bool fits32 = (long long)a.Cin * a.H * a.Wd * 4 < (1LL << 31) && (long long)a.Cout * a.Ho * a.Wo * 4 < (1LL << 31);  // buffer offsets
-    if (a.tiles_x != 1 || !fits32) return 0;
+    if (a.tiles_x != 1 || !fits32 || a.ks != 3 || a.pad != 1) return 0;
     if (NG == 3 && MG == 1 && c4 <= 1 && jx <= 4) return 6;  // RGB stem
     if (NG == 9 && MG == 1 && c4 <= 4 && jx <= 4) return 1;
     if (NG == 9 && MG == 2 && c4 <= 4 && jx <= 9) return 2;
@@ -1711,7 +1994,7 @@ struct BnOperand {  // statistics of the batch normalisation applied to x while 
 
 // slab kernel of aq_conv_wgrad; *nslab_out = number of slabs written to workspace ([nslab][Cout*Cin*9])
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn = nullptr);
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn = nullptr, int ks = 3, int pad = 1);
 
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
                   void *workspace, size_t workspace_bytes, void *stream)
@@ -1720,10 +2003,10 @@ int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, in
     if (int rc = check_conv("aq_conv_wgrad", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
     AQ_REQUIRE(dW, -EFAULT, "aq_conv_wgrad: NULL dW");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nW = Cout * Cin * 9;
+    const int nW = Cout * Cin * ksize * ksize;
     int nslab = 0;
     if (N > 0)
-        if (int rc = wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, st, &nslab)) return rc;
+        if (int rc = wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, st, &nslab, nullptr, ksize, pad)) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(static_cast<const float *>(workspace), dW, nW)), dim3(256), 0, st,
                        static_cast<const float *>(workspace), dW, nW, nslab);
     return check_launch("aq_conv_wgrad(reduce)");
@@ -1737,7 +2020,7 @@ int aq_conv_wgrad_partial(const float *x, const float *dy, int N, int Cin, int H
     AQ_REQUIRE(nslab, -EFAULT, "aq_conv_wgrad_partial: NULL nslab");
     *nslab = 0;
     if (N == 0) return 0;
-    return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab);
+    return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab, nullptr, ksize, pad);
 }
 
 int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
@@ -1766,12 +2049,9 @@ int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
 int aq_bnconv_supported(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
 {
     using namespace aq;
-    if (check_conv("aq_bnconv_supported", N, Cin, H, Wd, Cout, ksize, stride, pad) || N < 1) return 0;
+    if (check_conv("aq_bnconv_supported", N, Cin, H, Wd, Cout, ksize, stride, pad) || N < 1 || ksize != 3 || pad != 1) return 0;
     ConvArgs a = {};
-    a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
-    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
-    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
     if (launch_gemm<MODE_FWD>(a, N, nullptr, "aq_bnconv_supported", true) != 1) return 0;
     WgradArgs w = {};
     w.N = N; w.Cin = Cin; w.H = H; w.Wd = Wd; w.Cout = Cout; w.stride = stride;
@@ -1802,10 +2082,7 @@ int aq_bnconv_fwd(const float *x, const float *gamma, const float *beta, float *
     if (int rc = launch_bn_stats(x, static_cast<float2 *>(workspace), g, st)) return rc;
     ConvArgs a = {};
     a.in = x; a.W = W; a.out = y; a.res = res;
-    a.N = N; a.Cin = Cin; a.Cout = Cout;
-    a.M = Cout; a.KC = Cin; a.K = Cin * 9;
-    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
-    a.IH = H; a.IW = Wd; a.rs = stride; a.dil = 1;
+    conv_fwd_args(a, N, Cin, H, Wd, Cout, stride);
     a.bn_on = 1;
     a.bn = BnStatsIn{static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd,
                      eps, momentum};
@@ -1827,14 +2104,14 @@ int aq_bnconv_wgrad_partial(const float *x, const float *gamma, const float *bet
 }
 
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn)
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn, int ks, int pad)
 {
     using namespace aq;
     AQ_REQUIRE(x && dy, -EFAULT, "aq_conv_wgrad: NULL pointer");
     WgradArgs a = {};
     a.x = x; a.dy = dy; a.part = static_cast<float *>(workspace);
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
-    a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride;
+    a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
@@ -1893,12 +2170,12 @@ int aq_conv_bwd(const float *dy, const float *W, const float *x, float *dx, int 
     // plans of the two halves
     ConvArgs a = {};
     a.in = dy; a.W = W; a.out = dx;
-    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride);
+    conv_dgrad_args(a, N, Cin, H, Wd, Cout, stride, ksize, pad);
     ConvStatsPlan plan;
     launch_gemm<MODE_DGRAD>(a, N, nullptr, "aq_conv_bwd", true, &plan);
     WgradArgs w = {};
     w.x = x; w.dy = dy; w.part = static_cast<float *>(workspace);
-    w.N = N; w.Cin = Cin; w.H = H; w.Wd = Wd; w.Cout = Cout; w.stride = stride;
+    w.N = N; w.Cin = Cin; w.H = H; w.Wd = Wd; w.Cout = Cout; w.stride = stride; w.ks = ksize; w.pad = pad;
     int MG, NG;
     dim3 wgrid;
     size_t wlds, ws;

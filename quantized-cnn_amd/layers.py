@@ -119,30 +119,31 @@ class _Conv3x3(torch.autograd.Function):
     added in the input-gradient kernel's epilogue instead of by a separate accumulation launch."""
 
     @staticmethod
-    def forward(ctx, x, W, stride, dW_slot, res, holder=None, split=False):
+    def forward(ctx, x, W, stride, dW_slot, res, holder=None, split=False, pad=1):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
-        ctx.stride, ctx.dW_slot = stride, dW_slot
+        ctx.stride, ctx.dW_slot, ctx.pad = stride, dW_slot, pad
         res = res.contiguous() if res is not None else None
         if holder is None:
-            y = ops.conv_forward(x, W, stride, res)
+            y = ops.conv_forward(x, W, stride, res, pad=pad)
         else:
-            y, holder["stats"] = ops.conv_forward(x, W, stride, res, stats=True)
+            y, holder["stats"] = ops.conv_forward(x, W, stride, res, stats=True, pad=pad)
         return (y, x.view_as(x)) if split else y
 
     @staticmethod
     def backward(ctx, dy, dalias=None):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        tail = (None, None, (dy if ctx.needs_input_grad[4] else None), None, None)
-        if _fused_backward_ok(ctx.dW_slot) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dalias is None:
+        tail = (None, None, (dy if ctx.needs_input_grad[4] else None), None, None, None)
+        usual = W.shape[2] == 3 and ctx.pad == 1
+        if usual and _fused_backward_ok(ctx.dW_slot) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dalias is None:
             dx, _, ws, nslab = ops.conv_backward(dy, W, x, ctx.stride)
             _wgrad_deferred.append((ws, ctx.dW_slot, nslab, x, dy))
             return (dx, None) + tail
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride, res=dalias.contiguous() if dalias is not None else None)
-        dW = _weight_grad(x, dy, ctx.stride, ctx.dW_slot) if ctx.needs_input_grad[1] else None
+            dx = ops.conv_dgrad(dy, W, x.shape, ctx.stride, res=dalias.contiguous() if dalias is not None else None, pad=ctx.pad)
+        dW = _weight_grad(x, dy, ctx.stride, ctx.dW_slot, int(W.shape[2]), ctx.pad) if ctx.needs_input_grad[1] else None
         return (dx, dW) + tail
 
 
@@ -159,20 +160,20 @@ def _fused_backward_ok(dW_slot):
     return FUSE_CONV_BACKWARD and _wgrad_deferred is not None and dW_slot is not None and _wgrad_stream is None
 
 
-def _weight_grad(x, dy, stride, dW_slot):
-    """dW of a 3x3 convolution for autograd, or None when it is left in dW_slot by the batched reduction at
+def _weight_grad(x, dy, stride, dW_slot, ks=3, pad=1):
+    """dW of a convolution for autograd, or None when it is left in dW_slot by the batched reduction at
     the end of the backward pass (nothing is handed to autograd then: it would clone the slot into the
     leaf's .grad)."""
     if _wgrad_deferred is not None and dW_slot is not None:
         if _wgrad_stream is not None:
             _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
             with torch.cuda.stream(_wgrad_stream):
-                ws, nslab = ops.conv_wgrad_partial(x, dy, stride)
+                ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
         else:
-            ws, nslab = ops.conv_wgrad_partial(x, dy, stride)
+            ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
         _wgrad_deferred.append((ws, dW_slot, nslab, x, dy))
         return None
-    return ops.conv_wgrad(x, dy, stride, out=dW_slot)
+    return ops.conv_wgrad(x, dy, stride, out=dW_slot, ks=ks, pad=pad)
 
 
 # The convolution's epilogue can leave the channel statistics of its output behind, so that the batch
@@ -183,11 +184,11 @@ CONV_EMITS_BN_STATS = True
 _STATS_ATTR = "_aq_conv_stats"
 
 
-def conv3x3(x, W, stride, dW_slot, res=None, stats=False, split=False):
-    """_Conv3x3 on (x, W); stats=True asks the kernel for the output's channel statistics as well; split=True
-    returns (y, x') with x' = x for an identity shortcut."""
+def conv3x3(x, W, stride, dW_slot, res=None, stats=False, split=False, pad=1):
+    """_Conv3x3 on (x, W) (any supported kernel size; 3x3 / padding 1 is the tuned case); stats=True asks the kernel
+    for the output's channel statistics as well; split=True returns (y, x') with x' = x for an identity shortcut."""
     holder = {} if (stats and CONV_EMITS_BN_STATS) else None
-    out = _Conv3x3.apply(x, W, stride, dW_slot, res, holder, split)
+    out = _Conv3x3.apply(x, W, stride, dW_slot, res, holder, split, pad)
     y = out[0] if split else out
     if holder is not None and holder.get("stats") is not None:
         setattr(y, _STATS_ATTR, (holder["stats"], y._version))
@@ -511,18 +512,27 @@ class QConv2d(_QuantBase):
         with split=True returns (y, x') where x' is x for the caller's shortcut path, with split=(front, back)
         (y, s) where s is the pooled and channel-padded shortcut of x."""
         assert len(x.shape) == 4
-        if self.ksize != 3 or self.padding != 1 or self.stride not in (1, 2):
-            raise NotImplementedError("the HIP convolution implements ksize=3, padding=1, stride 1|2 "
+        if self.ksize not in (1, 3, 5, 7) or not (0 <= self.padding < self.ksize) or self.stride not in (1, 2):
+            raise NotImplementedError("the HIP convolution implements ksize 1|3|5|7, padding < ksize, stride 1|2 "
                                       "(got ksize=%d padding=%d stride=%d)" % (self.ksize, self.padding, self.stride))
         w, slot = self.synthesize()
+        usual = self.ksize == 3 and self.padding == 1  # the reference's layers: kernels with fused epilogues
         if self.mode == "train":
-            if bn is not None:
+            if bn is not None and usual:
                 return bn_relu_conv(bn, x, w, self.stride, slot, res, split, stats=self.training)
-            return conv3x3(x, w, self.stride, slot, res, stats=self.training, split=bool(split))
+            if bn is not None:
+                if isinstance(split, tuple):
+                    z, xs = bn_relu(bn, x, split=True)
+                    return conv3x3(z, w, self.stride, slot, res, pad=self.padding), _Shortcut.apply(xs, *split)
+                if split:
+                    z, xs = bn_relu(bn, x, split=True)
+                    return conv3x3(z, w, self.stride, slot, res, pad=self.padding), xs
+                return conv3x3(bn_relu(bn, x), w, self.stride, slot, res, pad=self.padding)
+            return conv3x3(x, w, self.stride, slot, res, stats=self.training and usual, split=bool(split), pad=self.padding)
         xs = x
         if bn is not None:
             x = bn_relu(bn, x)
-        y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], w["q"] if "q" in w else self.q_level.detach(), self.stride)
+        y = ops.conv_forward_codes(x.contiguous(), w["idx"][0], w["q"] if "q" in w else self.q_level.detach(), self.stride, self.padding)
         y = y if res is None else y + res
         if isinstance(split, tuple):
             return y, _Shortcut.apply(xs, *split)

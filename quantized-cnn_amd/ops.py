@@ -157,26 +157,27 @@ def synth_backward_adam(p_list, q_list, beta, dW_list, exp_avg, exp_avg_sq, step
 
 # ------------------------------------------------------------------------------------ convolution
 
-def _conv_dims(x_shape, Cout, stride):
+def _conv_dims(x_shape, Cout, stride, ks=3, pad=1):
     N, Cin, H, Wd = x_shape
-    return [int(N), int(Cin), int(H), int(Wd), int(Cout), 3, int(stride), 1]
+    return [int(N), int(Cin), int(H), int(Wd), int(Cout), int(ks), int(stride), int(pad)]
 
 
-def conv_out_shape(x_shape, Cout, stride):
+def conv_out_shape(x_shape, Cout, stride, ks=3, pad=1):
     N, _, H, Wd = x_shape
-    return (N, Cout, (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1)
+    return (N, Cout, (H + 2 * pad - ks) // stride + 1, (Wd + 2 * pad - ks) // stride + 1)
 
 
-def conv_forward(x, W, stride=1, res=None, stats=False):
-    """y = conv2d(x, W, stride, padding=1) [+ res], W (Cout, Cin, 3, 3)  (adp_qtz_fan.py:574-601;
-    res: the shortcut added after conv2, :676-677).
+def conv_forward(x, W, stride=1, res=None, stats=False, pad=1):
+    """y = conv2d(x, W, stride, padding=pad) [+ res], W (Cout, Cin, k, k), k in 1, 3, 5, 7  (adp_qtz_fan.py:574-601;
+    res: the shortcut added after conv2, :676-677).  3x3 / padding 1, the reference's layers, has the tuned kernels.
     stats=True returns (y, st): st = (buffer, descriptor) holds per-workgroup channel statistics of y written
     by the convolution's epilogue, which bn_relu_forward(y, ..., conv_stats=st) takes in place of its own
     statistics pass; st is None for shapes without that epilogue."""
-    if W.dim() != 4 or W.shape[2] != 3 or W.shape[3] != 3 or x.dim() != 4 or W.shape[1] != x.shape[1]:
-        raise ValueError("conv_forward: x %s / W %s: need NCHW input and (Cout, Cin, 3, 3) weights" % (tuple(x.shape), tuple(W.shape)))
-    y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride), dtype=torch.float32, device=x.device)
-    dims = _conv_dims(x.shape, W.shape[0], stride)
+    if W.dim() != 4 or W.shape[2] != W.shape[3] or x.dim() != 4 or W.shape[1] != x.shape[1]:
+        raise ValueError("conv_forward: x %s / W %s: need NCHW input and (Cout, Cin, k, k) weights" % (tuple(x.shape), tuple(W.shape)))
+    ks = int(W.shape[2])
+    y = torch.empty(conv_out_shape(x.shape, W.shape[0], stride, ks, pad), dtype=torch.float32, device=x.device)
+    dims = _conv_dims(x.shape, W.shape[0], stride, ks, pad)
     if res is not None and tuple(res.shape) != tuple(y.shape):
         raise ValueError("conv_forward: res %s does not match the output %s" % (tuple(res.shape), tuple(y.shape)))
     if stats:
@@ -196,36 +197,38 @@ def conv_forward(x, W, stride=1, res=None, stats=False):
     return (y, None) if stats else y
 
 
-def conv_forward_codes(x, idx, q, stride=1):
-    """Hard-mode conv: weights given as uint8 codes (Cout, Cin, 3, 3) + levels q (L,)."""
-    if idx.dim() != 4 or idx.shape[1] != x.shape[1]:
+def conv_forward_codes(x, idx, q, stride=1, pad=1):
+    """Hard-mode conv: weights given as uint8 codes (Cout, Cin, k, k) + levels q (L,)."""
+    if idx.dim() != 4 or idx.shape[1] != x.shape[1] or idx.shape[2] != idx.shape[3]:
         raise ValueError("conv_forward_codes: idx %s does not match x %s" % (tuple(idx.shape), tuple(x.shape)))
-    y = torch.empty(conv_out_shape(x.shape, idx.shape[0], stride), dtype=torch.float32, device=x.device)
+    ks = int(idx.shape[2])
+    y = torch.empty(conv_out_shape(x.shape, idx.shape[0], stride, ks, pad), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().aq_conv_fwd_codes(_lib.ptr(x, name="x"), _lib.ptr(idx, torch.uint8, "idx"), _lib.ptr(q, name="q"), int(q.numel()),
-                                            _lib.ptr(y), *_conv_dims(x.shape, idx.shape[0], stride), _lib.stream()))
+                                            _lib.ptr(y), *_conv_dims(x.shape, idx.shape[0], stride, ks, pad), _lib.stream()))
     return y
 
 
-def conv_dgrad(dy, W, x_shape, stride=1, bn=None, res=None):
+def conv_dgrad(dy, W, x_shape, stride=1, bn=None, res=None, pad=1):
     """dx = d loss / d x of conv_forward.  bn = (xb, gamma, beta, save_mean, save_rstd) says that x was
     relu(batch_norm(xb)): the result is then (dx, sums), where sums = (buffer, descriptor) holds the
     per-workgroup reductions that bn_relu_backward(dx, xb, ..., dgrad_sums=sums) takes in place of its own
     reduction pass (None for shapes without that epilogue).  res: tensor of x's shape added to dx in the
     kernel's epilogue (the gradient arriving over an identity shortcut); not together with bn."""
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
-    if tuple(dy.shape) != conv_out_shape(x_shape, W.shape[0], stride):
+    ks = int(W.shape[2])
+    if tuple(dy.shape) != conv_out_shape(x_shape, W.shape[0], stride, ks, pad):
         raise ValueError("conv_dgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x_shape)))
     if res is not None:
         if bn is not None or tuple(res.shape) != tuple(x_shape):
             raise ValueError("conv_dgrad: res %s must have the shape of x %s and excludes bn" % (tuple(res.shape), tuple(x_shape)))
         _lib.check(_lib.lib().aq_conv_dgrad_add(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(res, name="res"), _lib.ptr(dx),
-                                                *_conv_dims(x_shape, W.shape[0], stride), _lib.stream()))
+                                                *_conv_dims(x_shape, W.shape[0], stride, ks, pad), _lib.stream()))
         return dx
     if bn is not None:
         xb, gamma, beta, mean, rstd = bn
         if tuple(xb.shape) != tuple(x_shape) or not xb.is_contiguous():
             raise ValueError("conv_dgrad: bn input %s must be contiguous with the shape of x %s" % (tuple(xb.shape), tuple(x_shape)))
-        dims = _conv_dims(x_shape, W.shape[0], stride)
+        dims = _conv_dims(x_shape, W.shape[0], stride, ks, pad)
         nbytes = _lib.lib().aq_conv_dgrad_bn_bytes(*dims) if x_shape[0] > 0 else 0
         if nbytes > 0:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
@@ -237,19 +240,20 @@ def conv_dgrad(dy, W, x_shape, stride=1, bn=None, res=None):
             return dx, (buf, desc)
         _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *dims, _lib.stream()))
         return dx, None
-    _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *_conv_dims(x_shape, W.shape[0], stride), _lib.stream()))
+    _lib.check(_lib.lib().aq_conv_dgrad(_lib.ptr(dy, name="dy"), _lib.ptr(W, name="W"), _lib.ptr(dx), *_conv_dims(x_shape, W.shape[0], stride, ks, pad),
+                                        _lib.stream()))
     return dx
 
 
-def conv_backward(dy, W, x, stride=1, bn=None):
+def conv_backward(dy, W, x, stride=1, bn=None, pad=1):
     """Both gradients of y = conv_forward(x, W, stride) from one call (one launch where the library has a
     kernel pair for the shape): -> (dx, sums, workspace, nslab).  dx / sums as conv_dgrad(dy, W, x.shape,
     stride, bn) (sums None without bn or without a reduction epilogue for the shape); workspace / nslab as
     conv_wgrad_partial(x, dy, stride), to be finished by conv_wgrad_reduce."""
-    Cout = W.shape[0]
-    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride) or W.shape[1] != x.shape[1]:
+    Cout, ks = W.shape[0], int(W.shape[2])
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride, ks, pad) or W.shape[1] != x.shape[1]:
         raise ValueError("conv_backward: dy %s / W %s do not match x %s" % (tuple(dy.shape), tuple(W.shape), tuple(x.shape)))
-    dims = _conv_dims(x.shape, Cout, stride)
+    dims = _conv_dims(x.shape, Cout, stride, ks, pad)
     dx = torch.empty_like(x)
     nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
@@ -271,25 +275,27 @@ def conv_backward(dy, W, x, stride=1, bn=None):
     return dx, sums, ws, nslab.value
 
 
-def conv_wgrad(x, dy, stride=1, out=None):
+def conv_wgrad(x, dy, stride=1, out=None, ks=3, pad=1):
     Cout = dy.shape[1]
-    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride, ks, pad):
         raise ValueError("conv_wgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
-    dW = out if out is not None else torch.empty((Cout, x.shape[1], 3, 3), dtype=torch.float32, device=x.device)
-    dims = _conv_dims(x.shape, Cout, stride)
+    dW = out if out is not None else torch.empty((Cout, x.shape[1], ks, ks), dtype=torch.float32, device=x.device)
+    if dW.numel() != Cout * x.shape[1] * ks * ks:
+        raise ValueError("conv_wgrad: out has %d elements, expected %d" % (dW.numel(), Cout * x.shape[1] * ks * ks))
+    dims = _conv_dims(x.shape, Cout, stride, ks, pad)
     nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     _lib.check(_lib.lib().aq_conv_wgrad(_lib.ptr(x, name="x"), _lib.ptr(dy, name="dy"), _lib.ptr(dW, name="dW"), *dims, ws.data_ptr(), nbytes, _lib.stream()))
     return dW
 
 
-def conv_wgrad_partial(x, dy, stride=1):
+def conv_wgrad_partial(x, dy, stride=1, ks=3, pad=1):
     """First stage of conv_wgrad only: -> (workspace tensor holding the slabs, number of slabs).  The
     caller reduces them later with conv_wgrad_reduce (several layers in one launch)."""
     Cout = dy.shape[1]
-    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride):
+    if tuple(dy.shape) != conv_out_shape(x.shape, Cout, stride, ks, pad):
         raise ValueError("conv_wgrad_partial: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
-    dims = _conv_dims(x.shape, Cout, stride)
+    dims = _conv_dims(x.shape, Cout, stride, ks, pad)
     nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     nslab = C.c_int(0)

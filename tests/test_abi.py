@@ -41,8 +41,10 @@ def test_argument_errors_are_reported_without_a_gpu():
     segs[0].L = 32
     assert lib.aq_synth_fwd(segs, 1, 1000.0, 0, None, 0, None) < 0
     assert b"beta" in lib.aq_last_error()
-    assert lib.aq_conv_fwd(None, None, None, 1, 3, 8, 8, 4, 5, 1, 2, None) < 0
+    assert lib.aq_conv_fwd(None, None, None, 1, 3, 8, 8, 4, 4, 1, 2, None) < 0
     assert b"3x3" in lib.aq_last_error()
+    assert lib.aq_conv_fwd(None, None, None, 1, 3, 8, 8, 4, 5, 1, 2, None) < 0  # a supported shape: fails on the pointers
+    assert b"NULL" in lib.aq_last_error()
     assert lib.aq_conv_wgrad_workspace_bytes(128, 16, 32, 32, 16, 3, 1, 1) > 0
 
 

@@ -1,0 +1,100 @@
+"""The general convolution kernels (any odd kernel size up to 7, any padding below it, stride 1 | 2, any channel
+count: the reference's MyConv2d.forward, adp_qtz_fan.py:574-601, is written for any ksize / stride / padding) against
+the CPU oracle, whose convolution is generic in the same parameters: forward, input gradient, weight gradient,
+hard-mode codes and the shortcut addition.  Tolerance 2e-5 of the result's scale (fp32, other summation order).
+Shapes: the ResNet-18 @ 224 layer shapes the 3x3 kernels of the ResNet-20 path cannot take (7x7 / stride 2 stem,
+1x1 / stride 2 projections, 128-512 channels) at reduced batch, plus ragged cases."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import quantized_cnn_amd.ops as ops
+DEV = "cuda"
+
+SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
+    (3, 64, 7, 2, 3, 64, 64, 2),       # ResNet-18 stem at reduced size
+    (3, 64, 7, 2, 3, 224, 224, 1),     # ... and at 224 x 224
+    (64, 64, 3, 1, 1, 56, 56, 1),      # layer1 (fits the tuned kernels)
+    (64, 128, 3, 2, 1, 56, 56, 1),     # layer2.0.conv1
+    (64, 128, 1, 2, 0, 56, 56, 2),     # layer2.0 projection
+    (128, 128, 3, 1, 1, 28, 28, 2),
+    (128, 256, 3, 2, 1, 28, 28, 1),
+    (256, 256, 3, 1, 1, 14, 14, 2),
+    (256, 512, 1, 2, 0, 14, 14, 2),
+    (512, 512, 3, 1, 1, 7, 7, 3),
+    (20, 24, 5, 1, 2, 9, 11, 2),       # 5x5, ragged everything
+    (16, 16, 3, 1, 0, 10, 10, 2),      # no padding
+    (5, 7, 3, 2, 2, 8, 8, 2),          # padding 2 on a 3x3
+    (70, 130, 3, 2, 1, 13, 9, 2),      # channel counts that are no multiples of 16
+    (8, 8, 1, 1, 0, 5, 5, 3),
+    (33, 17, 7, 1, 3, 12, 12, 1),
+]
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def near(got, want, what, rel=2e-5):
+    err = np.abs(got - want).max()
+    assert err <= rel * max(np.abs(want).max(), 1e-6), (what, err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_general_conv_forward_dgrad_wgrad_vs_oracle(shape):
+    cin, cout, ks, stride, pad, H, Wd, N = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.standard_normal((N, cin, H, Wd)).astype(np.float32)
+    W = (rs.standard_normal((cout, cin, ks, ks)) / np.sqrt(cin * ks * ks)).astype(np.float32)
+    y_ref = O.conv_fwd(x, W, stride, pad)
+    xd, Wdv = cu(x), cu(W)
+    y = ops.conv_forward(xd, Wdv, stride, pad=pad)
+    assert tuple(y.shape) == y_ref.shape
+    near(y.cpu().numpy(), y_ref, "y")
+    res = rs.standard_normal(y_ref.shape).astype(np.float32)
+    near(ops.conv_forward(xd, Wdv, stride, res=cu(res), pad=pad).cpu().numpy(), y_ref + res, "y + res")
+    dy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    dyd = cu(dy)
+    near(ops.conv_dgrad(dyd, Wdv, x.shape, stride, pad=pad).cpu().numpy(), O.conv_dgrad(dy, W, x.shape, stride, pad), "dx")
+    dW = ops.conv_wgrad(xd, dyd, stride, ks=ks, pad=pad)
+    assert tuple(dW.shape) == W.shape
+    near(dW.cpu().numpy(), O.conv_wgrad(x, dy, ks, stride, pad), "dW")
+    # deterministic
+    assert torch.equal(dW, ops.conv_wgrad(xd, dyd, stride, ks=ks, pad=pad))
+    assert torch.equal(y, ops.conv_forward(xd, Wdv, stride, pad=pad))
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 7, 2, 3, 40, 40, 2), (128, 128, 3, 1, 1, 14, 14, 2), (64, 128, 1, 2, 0, 16, 16, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_general_conv_from_codes(shape):
+    """Hard mode (adp_qtz_fan_test.py:304-331): W = q[idx] decoded inside the kernel."""
+    cin, cout, ks, stride, pad, H, Wd, N = shape
+    rs = np.random.RandomState(7 + sum(shape))
+    L = 32
+    idx = rs.randint(0, L, (cout, cin, ks, ks)).astype(np.uint8)
+    q = O.levels_hint(0.3, L)
+    x = rs.standard_normal((N, cin, H, Wd)).astype(np.float32)
+    y = ops.conv_forward_codes(cu(x), torch.from_numpy(idx).to(DEV), cu(q), stride, pad)
+    near(y.cpu().numpy(), O.conv_fwd(x, q[idx.astype(np.int64)], stride, pad), "y(codes)")
+
+
+def test_adjoint_identity_at_resnet18_sizes():
+    """<conv(x, W), dy> = <x, dgrad(dy, W)> = <W, wgrad(x, dy)> at a full-size layer (batch 16, 256 -> 256 channels at
+    14 x 14), where the oracle would take minutes: a size-independent property in float64 accumulation."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(16, 256, 14, 14, device=DEV, generator=g)
+    W = torch.randn(256, 256, 3, 3, device=DEV, generator=g) * 0.02
+    y = ops.conv_forward(x, W, 1)
+    dy = torch.randn(y.shape, device=DEV, generator=g)
+    a = float((y.double() * dy.double()).sum())
+    b = float((x.double() * ops.conv_dgrad(dy, W, x.shape, 1).double()).sum())
+    c = float((W.double() * ops.conv_wgrad(x, dy, 1).double()).sum())
+    scale = float((y.double().abs() * dy.double().abs()).sum())
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale
+    yt = torch.nn.functional.conv2d(x, W, padding=1)
+    assert (y - yt).abs().max().item() <= 1e-4 * yt.abs().max().item()  # (stock fp32 conv may use other arithmetic)

@@ -217,7 +217,11 @@ def test_module_api_details():
     with pytest.raises(RuntimeError):
         fan.MyConv2d(c, 4, 8, 3, 1, 1)(torch.randn(2, 4, 6, 6))  # CPU tensors: no fallback
     with pytest.raises(NotImplementedError):
-        fan.MyConv2d(c, 4, 8, 5, 1, 2).cuda()(x)
+        fan.MyConv2d(c, 4, 8, 4, 1, 2).cuda()(x)  # even kernel sizes have no kernel
+    big = fan.MyConv2d(c, 4, 8, 5, 1, 2).cuda()  # ksize / stride / padding are free in the reference (adp_qtz_fan.py:574-601)
+    yb = big(x)
+    Wb = big.synthesize()[0]
+    assert (yb - torch.nn.functional.conv2d(x, Wb.detach(), stride=1, padding=2)).abs().max().item() <= 2e-5 * yb.abs().max().item()
     lin = fan.MyLinear(c, 64, 10).cuda()
     assert lin.p_c.shape == (64, 10, 32) and lin(torch.randn(3, 64, device="cuda")).shape == (3, 10)
 
