@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 7
+#define AQ_ABI_VERSION 8
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -331,6 +331,52 @@ int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na,
                const float *sumsq_b, int nb, float l2_reg, float grad_scale, float *dlogits, float *out,
                void *stream);
+
+/* ---- Ternary and power-of-two quantisers of the papers the reference cites (README.md:3-29) -----------------
+ * The reference's scripts hold no implementation of them (only the citations and, in the file headers
+ * adp_qtz_fix.py:4-6, their names), so there is no reference code to cite line by line: the entry points below
+ * restate the published algorithms, and their CPU checker was written from the same papers (parity unpinned).
+ *   TWN (Li, Zhang, Liu 2016):  delta = 0.7 * mean|w|;  w~ = alpha * sign(w) where |w| > delta, 0 elsewhere,
+ *                               alpha = mean of |w| over |w| > delta; straight-through gradient dw = dw~.
+ *   TTQ (Zhu, Han, Mao, Dally 2017): w~ = +Wp where w > delta, -Wn where w < -delta (Wp, Wn learned, delta = t * max|w|
+ *                               in the paper; factor * mean|w| selectable); dw = Wp * dw~ / dw~ / Wn * dw~ by region,
+ *                               dWp = sum of dw~ over the positives, dWn = -(sum over the negatives).
+ *   INQ (Zhou et al. 2017):     weights join a frozen partition largest magnitudes first and are rounded there to
+ *                               {0, +-2^n2 .. +-2^n1}; the gradient of frozen weights is masked.
+ * One aq_tern_seg per layer; unused pointers may be NULL. */
+#define AQ_TERN_TWN 0
+#define AQ_TERN_TTQ 1
+#define AQ_TERN_INQ 2
+typedef struct aq_tern_seg {
+    const float *W;       /* [n] latent full-precision weights                                             */
+    int64_t n;
+    /* forward outputs */
+    uint8_t *codes;       /* [n] 0 = zero, 1 = positive, 2 = negative                                      */
+    uint8_t *packed;      /* [ceil(n/4)] the same codes, 2 bits each, code i in bits [2i, 2i+2) of the stream */
+    float *Wt;            /* [n] quantized weights q[code]                                                 */
+    float *stats;         /* [4] written: delta, positive scale, negative scale, number of non-zero codes  */
+    float *q;             /* [3] written: codebook {0, +pos, -neg} (for aq_conv_fwd_codes with L = 3)       */
+    const float *Wp, *Wn; /* [1] TTQ: learned scales (device memory)                                       */
+    /* backward */
+    const uint8_t *mask;  /* [n] INQ: 1 = trainable, 0 = frozen                                            */
+    const float *dWt;     /* [n] d loss / d w~                                                             */
+    float *dW;            /* [n] d loss / d w (latent)                                                     */
+    float *dWp, *dWn;     /* [1] TTQ: d loss / d Wp, d loss / d Wn                                          */
+} aq_tern_seg;
+size_t aq_tern_workspace_bytes(const aq_tern_seg *segs, int nseg);
+/* Quantise nseg layers (at most 32 per call): per layer a reduction of |w| for the threshold
+ * delta = factor * mean|w| (threshold_from_max != 0: factor * max|w|), then codes / packed codes / scales / codebook
+ * (and Wt).  mode: AQ_TERN_TWN or AQ_TERN_TTQ.  Reductions run in a fixed order (deterministic). */
+int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int threshold_from_max, void *workspace,
+                size_t workspace_bytes, void *stream);
+/* Gradient of the latent weights (and of the TTQ scales) from d loss / d w~, one pass; mode AQ_TERN_TWN, _TTQ (uses
+ * stats[0] = delta as aq_tern_fwd left it) or _INQ (mask). */
+int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, size_t workspace_bytes, void *stream);
+/* One INQ partition step, in place: every weight with mask 1 and |w| >= tau is rounded to its power-of-two level
+ * (exponents n2..n1, or 0) and its mask cleared; codes (may be NULL): 255 = still trainable, 0 = zero,
+ * 1 + 2 * (k - n2) + (w < 0) for +-2^k.  The caller derives tau from the magnitude quantile of the stage and
+ * n1 = floor(log2(4 * max|w| / 3)), n2 = n1 + 1 - 2^(bits-1) / 2 once, before the first stage. */
+int aq_inq_partition(float *W, uint8_t *mask, uint8_t *codes, long long n, float tau, int n1, int n2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -436,3 +436,98 @@ void aqo_set_num_threads(int n)
     (void)n;
 #endif
 }
+
+/* ------------------------------------------------ ternary / power-of-two quantisers ---
+ * PARITY UNPINNED - no reference implementation.  The reference cites these methods (README.md:3-29) but its
+ * scripts implement none of them, and the linked repositories are not available here; the functions below
+ * restate the published algorithms:
+ *   TWN  Li, Zhang, Liu, "Ternary Weight Networks" (2016), eq. 4-6: delta = 0.7 * E|w|, alpha = mean of |w| above delta
+ *   TTQ  Zhu, Han, Mao, Dally, "Trained Ternary Quantization" (2017), eq. 6-8 (scale gradients as autograd of the forward
+ *        formula gives them: dWn carries the minus sign of w~ = -Wn)
+ *   INQ  Zhou et al., "Incremental Network Quantization" (2017), eq. 3-4 (level rule) and eq. 8 (masked update) */
+void aqo_tern_stats(const float *w, int64_t n, double *mean_abs, double *max_abs)
+{
+    double s = 0.0, m = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = fabs((double)w[i]);
+        s += a;
+        if (a > m) m = a;
+    }
+    *mean_abs = n ? s / (double)n : 0.0;
+    *max_abs = m;
+}
+
+/* codes for a given threshold: 0 where |w| <= delta, 1 where w > delta, 2 where w < -delta; sums for alpha */
+void aqo_tern_codes(const float *w, int64_t n, float delta, uint8_t *codes, double *sum_abs_nz, int64_t *npos, int64_t *nneg)
+{
+    double s = 0.0;
+    int64_t p = 0, q = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float x = w[i];
+        const uint8_t c = x > delta ? 1 : (x < -delta ? 2 : 0);
+        if (codes) codes[i] = c;
+        if (c) s += fabs((double)x);
+        p += c == 1;
+        q += c == 2;
+    }
+    *sum_abs_nz = s; *npos = p; *nneg = q;
+}
+
+/* mode 0 TWN: dw = dwt.  mode 1 TTQ: dw scaled by region, dwp / dwn.  mode 2 INQ: dw = mask ? dwt : 0 */
+void aqo_tern_bwd(const float *w, const float *dwt, int64_t n, int mode, float delta, float pos, float neg, const uint8_t *mask,
+                  float *dw, double *dwp, double *dwn)
+{
+    double sp = 0.0, sn = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float d = dwt[i];
+        if (mode == 1) {
+            if (w[i] > delta) { sp += (double)d; d = d * pos; }
+            else if (w[i] < -delta) { sn += (double)d; d = d * neg; }
+        } else if (mode == 2) {
+            d = mask[i] ? d : 0.0f;
+        }
+        dw[i] = d;
+    }
+    if (dwp) *dwp = sp;
+    if (dwn) *dwn = -sn;
+}
+
+/* INQ level of a magnitude a > 0 for exponents n2..n1: the power of two beta = 2^k with (alpha + beta) / 2 <= a < 3 beta / 2,
+ * alpha = beta / 2 (alpha = 0 for k = n2); 0 below 2^(n2-1); 2^n1 at and above 1.5 * 2^n1.  Returns k, or INT_MIN for 0. */
+static int inq_level(float a, int n1, int n2)
+{
+    if (!(a > 0.0f)) return -2147483647 - 1;
+    int e;
+    const float m = frexpf(a, &e);  /* a = m * 2^e, m in [0.5, 1) */
+    int k = (m >= 0.75f) ? e : e - 1;   /* a in [0.75 * 2^k, 1.5 * 2^k) */
+    if (k < n2) k = (a >= ldexpf(1.0f, n2 - 1)) ? n2 : (-2147483647 - 1);
+    if (k > n1) k = n1;
+    return k;
+}
+
+void aqo_inq_partition(float *w, uint8_t *mask, uint8_t *codes, int64_t n, float tau, int n1, int n2)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float x = w[i];
+        if (mask[i] && fabsf(x) >= tau) {
+            const int k = inq_level(fabsf(x), n1, n2);
+            const float qv = k == (-2147483647 - 1) ? 0.0f : ldexpf(1.0f, k);
+            x = x < 0.0f ? -qv : qv;
+            w[i] = x;
+            mask[i] = 0;
+        }
+        if (codes) {
+            unsigned c = 255;
+            if (!mask[i]) {
+                if (x == 0.0f) c = 0;
+                else {
+                    int e;
+                    const float m = frexpf(fabsf(x), &e);
+                    const int k = e - 1;
+                    c = (m == 0.5f && k >= n2 && k <= n1) ? 1u + 2u * (unsigned)(k - n2) + (x < 0.0f ? 1u : 0u) : 254u;
+                }
+            }
+            codes[i] = (uint8_t)c;
+        }
+    }
+}

@@ -43,6 +43,13 @@ def lib():
         L.aqo_bn_relu_bwd.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp]
         L.aqo_adam_step.argtypes = [fp, fp, fp, fp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.aqo_adam_step.restype = None
+        u8p = C.POINTER(C.c_uint8)
+        L.aqo_tern_stats.argtypes = [fp, C.c_int64, dp, dp]
+        L.aqo_tern_codes.argtypes = [fp, C.c_int64, C.c_float, u8p, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.aqo_tern_bwd.argtypes = [fp, fp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, u8p, fp, dp, dp]
+        L.aqo_inq_partition.argtypes = [fp, u8p, u8p, C.c_int64, C.c_float, C.c_int, C.c_int]
+        for f in ("aqo_tern_stats", "aqo_tern_codes", "aqo_tern_bwd", "aqo_inq_partition"):
+            getattr(L, f).restype = None
         L.aqo_num_threads.restype = C.c_int
         L.aqo_set_num_threads.argtypes = [C.c_int]
         for f in ("aqo_synth_fwd", "aqo_synth_bwd", "aqo_conv_fwd", "aqo_conv_dgrad", "aqo_conv_wgrad",
@@ -280,3 +287,68 @@ def fan_bound(fan_in):
     import math
     gain = math.sqrt(2.0 / (1 + 5.0))
     return math.sqrt(3.0) * gain / math.sqrt(fan_in)
+
+
+# ---- ternary / power-of-two quantisers: PARITY UNPINNED (no reference implementation; restated from the papers
+# cited at /root/reference/README.md:3-29, see aq_oracle.c) ---------------------------------------------------------
+
+def tern_stats(w):
+    """-> (mean |w|, max |w|) in float64."""
+    a, ap = _f(w)
+    mean, mx = C.c_double(0.0), C.c_double(0.0)
+    lib().aqo_tern_stats(ap, a.size, C.byref(mean), C.byref(mx))
+    return mean.value, mx.value
+
+
+def tern_codes(w, delta):
+    """Codes for a GIVEN threshold (float32) -> dict(codes uint8 (shape of w), sum_abs float64, npos, nneg)."""
+    a, ap = _f(w)
+    codes = np.empty(a.shape, np.uint8)
+    s, p, q = C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+    lib().aqo_tern_codes(ap, a.size, float(np.float32(delta)), codes.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(s), C.byref(p), C.byref(q))
+    return {"codes": codes, "sum_abs": s.value, "npos": p.value, "nneg": q.value}
+
+
+def tern_forward(w, mode="twn", factor=0.7, threshold_from_max=False, Wp=None, Wn=None):
+    """TWN / TTQ forward in float64 statistics: -> dict(delta, pos, neg, codes, Wt float32)."""
+    mean, mx = tern_stats(w)
+    delta = np.float32(factor * (mx if threshold_from_max else mean))
+    r = tern_codes(w, delta)
+    if mode == "ttq":
+        pos, neg = np.float32(Wp), np.float32(Wn)
+    else:
+        cnt = r["npos"] + r["nneg"]
+        pos = neg = np.float32(r["sum_abs"] / cnt) if cnt else np.float32(0.0)
+    q = np.array([0.0, pos, -neg], np.float32)
+    return {"delta": delta, "pos": pos, "neg": neg, "codes": r["codes"], "Wt": q[r["codes"]], "count": r["npos"] + r["nneg"]}
+
+
+def tern_backward(w, dwt, mode, delta=0.0, pos=1.0, neg=1.0, mask=None):
+    """-> (dw float32, dWp, dWn float64).  mode: "twn" | "ttq" | "inq"."""
+    a, ap = _f(w)
+    g, gp = _f(dwt)
+    dw = np.empty_like(a)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    dwp, dwn = C.c_double(0.0), C.c_double(0.0)
+    lib().aqo_tern_bwd(ap, gp, a.size, {"twn": 0, "ttq": 1, "inq": 2}[mode], float(np.float32(delta)), float(np.float32(pos)),
+                       float(np.float32(neg)), m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None,
+                       dw.ctypes.data_as(C.POINTER(C.c_float)), C.byref(dwp), C.byref(dwn))
+    return dw, dwp.value, dwn.value
+
+
+def inq_exponents(max_abs, bits=5):
+    """n1 = floor(log2(4 s / 3)), n2 = n1 + 1 - 2^(bits-1) / 2  (Zhou et al. 2017, eq. 3)."""
+    import math
+    n1 = int(math.floor(math.log2(4.0 * float(max_abs) / 3.0)))
+    return n1, n1 + 1 - (2 ** (bits - 1)) // 2
+
+
+def inq_partition(w, mask, tau, n1, n2):
+    """One partition step on copies: -> (w, mask, codes)."""
+    a = np.array(w, dtype=np.float32, copy=True, order="C")
+    m = np.array(mask, dtype=np.uint8, copy=True, order="C")
+    codes = np.empty(a.shape, np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().aqo_inq_partition(a.ctypes.data_as(C.POINTER(C.c_float)), m.ctypes.data_as(u8), codes.ctypes.data_as(u8), a.size,
+                            float(np.float32(tau)), int(n1), int(n2))
+    return a, m, codes

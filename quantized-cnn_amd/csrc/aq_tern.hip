@@ -1,0 +1,525 @@
+// Ternary / power-of-two weight quantisers of the papers the reference cites (README.md:3-29): Ternary Weight
+// Networks (Li, Zhang, Liu 2016), Trained Ternary Quantization (Zhu, Han, Mao, Dally 2017) and Incremental Network
+// Quantization (Zhou et al. 2017).  The reference's scripts contain none of them (only the citations), so these
+// kernels restate the published algorithms; their CPU checker (oracle/aq_oracle.c, aqo_tern_* / aqo_inq_*) is
+// written from the same papers: parity unpinned - no reference implementation.
+//
+//   forward (all layers of a model in one call, five small launches):
+//     A  per-wavefront partials of (sum |w|, max |w|)                     [HBM pass 1 over w]
+//     B  one workgroup per layer: partials -> delta = f * mean|w|  (or f * max|w|)
+//     C  codes: 0 where |w| <= delta, 1 where w > delta, 2 where w < -delta; optionally the same codes packed
+//        2 bits each, and the decoded weights q[code]; partials of (sum of |w| above delta, their count,
+//        positives, negatives)                                            [HBM pass 2 over w]
+//     D  one workgroup per layer: TWN alpha = mean of |w| above delta, codebook q = {0, +pos, -neg}
+//     E  (TWN only, when decoded weights are wanted) wt = q[code]
+//   backward (one launch + one reduction launch):
+//     straight-through gradient of the latent weights, scaled as TTQ prescribes, with the two scale gradients
+//     as masked sums; or the gradient masked by INQ's partition.
+// All cross-element sums are fixed-order (per-lane chain, wavefront butterfly, per-wavefront partial, then a
+// fixed-order second stage): run-to-run deterministic, no atomics.
+#include "aq_common.h"
+#include "../../include/aq_hip.h"
+
+#include <algorithm>
+
+namespace aq {
+
+constexpr int TERN_MAX_SEGS = 32;
+constexpr int TERN_ELEMS_PER_WAVE = 64 * 4 * 8;  // 8 coalesced 16-byte loads per lane
+
+struct TernSegDev {
+    const float *w;
+    const float *dwt;
+    const uint8_t *mask;   // INQ: 1 = still trainable, 0 = frozen
+    uint8_t *codes, *packed;
+    float *wt, *dw;
+    float *stats;          // [4] delta, pos, neg, nonzero count
+    float *q;              // [3] codebook
+    const float *wp, *wn;
+    float *dwp, *dwn;
+    float *part;           // per-wavefront partials of this layer
+    long long n;
+    int blk0, nwave;
+};
+struct TernTab {
+    int nseg;
+    TernSegDev s[TERN_MAX_SEGS];
+};
+
+__device__ __forceinline__ int tern_segment(const TernTab &tab)
+{
+    int si = 0;
+    for (int i = 1; i < tab.nseg; ++i)
+        if ((int)blockIdx.x >= tab.s[i].blk0) si = i;
+    return si;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// element range [e0, e1) of wavefront `wt` of a layer, and this lane's share: elements e0 + 256*u + 4*lane + k
+__device__ __forceinline__ void load8(const float *__restrict__ w, long long e0, long long n, int lane, float (&v)[8][4], bool vec)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+        if (vec && e + 3 < n) {
+            const float4 t = *reinterpret_cast<const float4 *>(w + e);
+            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = e + k < n ? w[e + k] : 0.0f;
+        }
+    }
+}
+
+// A: partials (sum |w|, max |w|) per wavefront
+__global__ __launch_bounds__(256) void tern_absstat_kernel(const TernTab tab)
+{
+    const int si = tern_segment(tab);
+    const TernSegDev &s = tab.s[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
+    if (wt >= s.nwave) return;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    float v[8][4];
+    load8(s.w, e0, s.n, lane, v, ((uintptr_t)s.w & 15) == 0);
+    float sum = 0.0f, mx = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = fabsf(v[u][k]);
+            sum += a;
+            mx = fmaxf(mx, a);
+        }
+    sum = wave_sum(sum);
+    mx = wave_max(mx);
+    if (lane == 0) {
+        s.part[2 * wt] = sum;
+        s.part[2 * wt + 1] = mx;
+    }
+}
+
+// fixed-order sum of `cnt` strided values: thread t adds t, t+256, ..; then a halving tree over the threads
+__device__ __forceinline__ float block_sum_strided(const float *p, int cnt, int stride, float *sh)
+{
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < cnt; i += 256) a += p[(long long)i * stride];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_max_strided(const float *p, int cnt, int stride, float *sh)
+{
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < cnt; i += 256) a = fmaxf(a, p[(long long)i * stride]);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// B: delta of every layer (one workgroup per layer)
+__global__ __launch_bounds__(256) void tern_delta_kernel(const TernTab tab, const float factor, const int thr_max)
+{
+    __shared__ float sh[256];
+    const TernSegDev &s = tab.s[blockIdx.x];
+    const float sum = block_sum_strided(s.part, s.nwave, 2, sh);
+    const float mx = block_max_strided(s.part + 1, s.nwave, 2, sh);
+    if (threadIdx.x == 0) {
+        const float mean = sum / (float)s.n;
+        s.stats[0] = factor * (thr_max ? mx : mean);
+    }
+}
+
+// C: codes (+ packed codes, decoded weights when the codebook is already known) and partials of the second reduction
+template <bool TTQ>
+__global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
+{
+    const int si = tern_segment(tab);
+    const TernSegDev &s = tab.s[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
+    if (wt >= s.nwave) return;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    const float delta = s.stats[0];
+    float pos = 0.0f, neg = 0.0f;
+    if (TTQ) {
+        pos = s.wp[0];
+        neg = s.wn[0];
+    }
+    float v[8][4];
+    const bool vec = ((uintptr_t)s.w & 15) == 0;
+    load8(s.w, e0, s.n, lane, v, vec);
+    float sabs = 0.0f, npos = 0.0f, nneg = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+        unsigned c4 = 0, p1 = 0;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = v[u][k];
+            const unsigned c = x > delta ? 1u : (x < -delta ? 2u : 0u);
+            c4 |= c << (8 * k);
+            p1 |= c << (2 * k);
+            sabs += c ? fabsf(x) : 0.0f;
+            npos += c == 1u ? 1.0f : 0.0f;
+            nneg += c == 2u ? 1.0f : 0.0f;
+            o[k] = c == 1u ? pos : (c == 2u ? -neg : 0.0f);
+        }
+        if (s.codes) {
+            if (e + 3 < s.n && ((uintptr_t)s.codes & 3) == 0) *reinterpret_cast<unsigned *>(s.codes + e) = c4;
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k < s.n) s.codes[e + k] = (uint8_t)(c4 >> (8 * k));
+            }
+        }
+        if (s.packed) {
+            // the four bytes of a lane quad form one 32-bit word (16 codes): gathered with quad permutes
+            const int b0 = __builtin_amdgcn_update_dpp(0, (int)p1, 0x00, 0xF, 0xF, false);  // quad_perm [0,0,0,0]
+            const int b1 = __builtin_amdgcn_update_dpp(0, (int)p1, 0x55, 0xF, 0xF, false);  // [1,1,1,1]
+            const int b2 = __builtin_amdgcn_update_dpp(0, (int)p1, 0xAA, 0xF, 0xF, false);  // [2,2,2,2]
+            const int b3 = __builtin_amdgcn_update_dpp(0, (int)p1, 0xFF, 0xF, 0xF, false);  // [3,3,3,3]
+            const unsigned word = (unsigned)b0 | ((unsigned)b1 << 8) | ((unsigned)b2 << 16) | ((unsigned)b3 << 24);
+            if ((lane & 3) == 0 && e < s.n) {
+                const long long byte0 = e >> 2;  // e is a multiple of 16 here
+                const long long nbytes = (s.n + 3) >> 2;
+                if (byte0 + 3 < nbytes && ((uintptr_t)s.packed & 3) == 0) *reinterpret_cast<unsigned *>(s.packed + byte0) = word;
+                else
+                    for (int b = 0; b < 4; ++b)
+                        if (byte0 + b < nbytes) s.packed[byte0 + b] = (uint8_t)(word >> (8 * b));
+            }
+        }
+        if (TTQ && s.wt) {
+            if (vec && ((uintptr_t)s.wt & 15) == 0 && e + 3 < s.n) *reinterpret_cast<float4 *>(s.wt + e) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k < s.n) s.wt[e + k] = o[k];
+            }
+        }
+    }
+    sabs = wave_sum(sabs);
+    npos = wave_sum(npos);
+    nneg = wave_sum(nneg);
+    if (lane == 0) {
+        s.part[4 * wt] = sabs;
+        s.part[4 * wt + 1] = npos;
+        s.part[4 * wt + 2] = nneg;
+    }
+}
+
+// D: codebook of every layer.  TWN: alpha = mean of |w| above delta for both signs; TTQ: the learned scales.
+template <bool TTQ>
+__global__ __launch_bounds__(256) void tern_codebook_kernel(const TernTab tab)
+{
+    __shared__ float sh[256];
+    const TernSegDev &s = tab.s[blockIdx.x];
+    const float sabs = block_sum_strided(s.part, s.nwave, 4, sh);
+    const float npos = block_sum_strided(s.part + 1, s.nwave, 4, sh);
+    const float nneg = block_sum_strided(s.part + 2, s.nwave, 4, sh);
+    if (threadIdx.x == 0) {
+        const float cnt = npos + nneg;
+        float pos, neg;
+        if (TTQ) {
+            pos = s.wp[0];
+            neg = s.wn[0];
+        } else {
+            pos = neg = cnt > 0.0f ? sabs / cnt : 0.0f;
+        }
+        s.stats[1] = pos;
+        s.stats[2] = neg;
+        s.stats[3] = cnt;
+        s.q[0] = 0.0f;
+        s.q[1] = pos;
+        s.q[2] = -neg;
+    }
+}
+
+// E: wt = q[code]
+__global__ __launch_bounds__(256) void tern_decode_kernel(const TernTab tab)
+{
+    const int si = tern_segment(tab);
+    const TernSegDev &s = tab.s[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
+    if (wt >= s.nwave || !s.wt) return;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    const float q1 = s.q[1], q2 = s.q[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e + k < s.n) {
+                const unsigned c = s.codes[e + k];
+                s.wt[e + k] = c == 1u ? q1 : (c == 2u ? q2 : 0.0f);
+            }
+    }
+}
+
+// backward.  MODE 0 (TWN): dw = dwt (straight through).  MODE 1 (TTQ): dw = pos * dwt where w > delta, neg * dwt where
+// w < -delta, dwt in between; partials of sum dwt over the positives and over the negatives.  MODE 2 (INQ):
+// dw = dwt where mask != 0, else 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
+{
+    const int si = tern_segment(tab);
+    const TernSegDev &s = tab.s[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
+    if (wt >= s.nwave) return;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    float delta = 0.0f, pos = 1.0f, neg = 1.0f;
+    if (MODE == 1) {
+        delta = s.stats[0];
+        pos = s.wp[0];
+        neg = s.wn[0];
+    }
+    float g[8][4], v[8][4];
+    const bool vec = (((uintptr_t)s.dwt | (uintptr_t)s.dw | (uintptr_t)s.w) & 15) == 0;
+    load8(s.dwt, e0, s.n, lane, g, vec);
+    if (MODE == 1) load8(s.w, e0, s.n, lane, v, vec);
+    float sp = 0.0f, sn = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = g[u][k];
+            if (MODE == 1) {
+                const float x = v[u][k];
+                if (x > delta) {
+                    sp += d;
+                    d *= pos;
+                } else if (x < -delta) {
+                    sn += d;
+                    d *= neg;
+                }
+            } else if (MODE == 2) {
+                d = (e + k < s.n && s.mask[e + k]) ? d : 0.0f;
+            }
+            o[k] = d;
+        }
+        if (vec && e + 3 < s.n) *reinterpret_cast<float4 *>(s.dw + e) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < s.n) s.dw[e + k] = o[k];
+        }
+    }
+    if (MODE == 1) {
+        sp = wave_sum(sp);
+        sn = wave_sum(sn);
+        if (lane == 0) {
+            s.part[2 * wt] = sp;
+            s.part[2 * wt + 1] = sn;
+        }
+    }
+}
+
+// d loss / d Wp = sum over the positives of dwt;  d loss / d Wn = - sum over the negatives (w~ = -Wn there)
+__global__ __launch_bounds__(256) void tern_scale_grad_kernel(const TernTab tab)
+{
+    __shared__ float sh[256];
+    const TernSegDev &s = tab.s[blockIdx.x];
+    const float sp = block_sum_strided(s.part, s.nwave, 2, sh);
+    const float sn = block_sum_strided(s.part + 1, s.nwave, 2, sh);
+    if (threadIdx.x == 0) {
+        if (s.dwp) s.dwp[0] = sp;
+        if (s.dwn) s.dwn[0] = -sn;
+    }
+}
+
+// INQ (Zhou et al. 2017, section 2): weights still trainable (mask 1) whose magnitude reaches tau join the frozen
+// partition: w <- sign(w) * 2^k with k chosen by the paper's rule (the power of two beta with (alpha + beta) / 2
+// <= |w| < 3 beta / 2, alpha the next smaller level; 0 below 2^(n2-1); at most 2^n1), mask <- 0.  codes: for frozen
+// weights 0 = zero, 1 + 2 * (k - n2) + (w < 0) otherwise; 255 for weights still trainable.
+__global__ __launch_bounds__(256) void inq_partition_kernel(float *__restrict__ w, uint8_t *__restrict__ mask, uint8_t *__restrict__ codes, long long n,
+                                                            float tau, int n1, int n2)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float x = w[i];
+    unsigned m = mask[i];
+    if (m && fabsf(x) >= tau) {
+        const float a = fabsf(x);
+        const unsigned b = __builtin_bit_cast(unsigned, a);
+        int k = (int)((b >> 23) & 0xff) - 127 + ((b & 0x7fffffu) >= 0x400000u ? 1 : 0);  // 0.75 * 2^(k+1) = 1.5 * 2^k
+        float qv = 0.0f;
+        if ((b >> 23) == 0) k = -200;  // zero / subnormal
+        if (k < n2) k = a >= ldexpf(1.0f, n2 - 1) ? n2 : -200;
+        if (k > n1) k = n1;
+        if (k > -200) qv = ldexpf(1.0f, k);
+        x = x < 0.0f ? -qv : qv;
+        w[i] = x;
+        mask[i] = 0;
+        m = 0;
+    }
+    if (codes) {
+        unsigned c = 255;
+        if (!m) {
+            const float a = fabsf(x);
+            if (a == 0.0f) c = 0;
+            else {
+                const int k = (int)((__builtin_bit_cast(unsigned, a) >> 23) & 0xff) - 127;
+                c = (k >= n2 && k <= n1) ? 1u + 2u * (unsigned)(k - n2) + (x < 0.0f ? 1u : 0u) : 254u;  // 254: frozen value outside the level set
+            }
+        }
+        codes[i] = (uint8_t)c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+
+static inline int tern_waves(long long n) { return (int)((n + TERN_ELEMS_PER_WAVE - 1) / TERN_ELEMS_PER_WAVE); }
+
+static size_t tern_ws_bytes(const aq_tern_seg *segs, int nseg)
+{
+    size_t off = 0;
+    for (int i = 0; i < nseg; ++i) off += (((size_t)tern_waves(segs[i].n) * 4 * sizeof(float)) + 255) & ~(size_t)255;
+    return off;
+}
+
+static int tern_validate(const char *who, const aq_tern_seg *segs, int nseg)
+{
+    AQ_REQUIRE(segs && nseg >= 1 && nseg <= TERN_MAX_SEGS, -EINVAL, "%s: 1..%d layers per call (got %d)", who, TERN_MAX_SEGS, nseg);
+    for (int i = 0; i < nseg; ++i) {
+        AQ_REQUIRE(segs[i].n >= 1 && segs[i].n < (1LL << 40), -EINVAL, "%s: layer %d: bad element count", who, i);
+        AQ_REQUIRE(segs[i].W && ((uintptr_t)segs[i].W & 3) == 0, -EFAULT, "%s: layer %d: W is NULL or misaligned", who, i);
+    }
+    return 0;
+}
+
+static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTab &tab)
+{
+    tab.nseg = nseg;
+    size_t off = 0;
+    long long blocks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        TernSegDev &d = tab.s[i];
+        const aq_tern_seg &s = segs[i];
+        d.w = s.W; d.dwt = s.dWt; d.mask = s.mask; d.codes = s.codes; d.packed = s.packed; d.wt = s.Wt; d.dw = s.dW;
+        d.stats = s.stats; d.q = s.q; d.wp = s.Wp; d.wn = s.Wn; d.dwp = s.dWp; d.dwn = s.dWn;
+        d.n = s.n;
+        d.nwave = tern_waves(s.n);
+        d.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + off);
+        off += (((size_t)d.nwave * 4 * sizeof(float)) + 255) & ~(size_t)255;
+        d.blk0 = (int)blocks;
+        blocks += (d.nwave + 3) / 4;
+        if (blocks >= (1LL << 31)) return -1;
+    }
+    return (int)blocks;
+}
+
+} // namespace aq
+
+extern "C" {
+
+size_t aq_tern_workspace_bytes(const aq_tern_seg *segs, int nseg)
+{
+    if (!segs || nseg < 1 || nseg > aq::TERN_MAX_SEGS) return 0;
+    return aq::tern_ws_bytes(segs, nseg);
+}
+
+int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int threshold_from_max, void *workspace, size_t workspace_bytes,
+                void *stream)
+{
+    using namespace aq;
+    if (int rc = tern_validate("aq_tern_fwd", segs, nseg)) return rc;
+    AQ_REQUIRE(mode == AQ_TERN_TWN || mode == AQ_TERN_TTQ, -EINVAL, "aq_tern_fwd: mode %d (AQ_TERN_TWN or AQ_TERN_TTQ)", mode);
+    AQ_REQUIRE(factor >= 0.0f && factor == factor, -EDOM, "aq_tern_fwd: threshold factor %g", (double)factor);
+    bool decode = false;
+    for (int i = 0; i < nseg; ++i) {
+        AQ_REQUIRE(segs[i].stats && segs[i].q, -EFAULT, "aq_tern_fwd: layer %d: stats / q is NULL", i);
+        AQ_REQUIRE(mode != AQ_TERN_TTQ || (segs[i].Wp && segs[i].Wn), -EFAULT, "aq_tern_fwd: layer %d: TTQ needs Wp and Wn", i);
+        AQ_REQUIRE(mode == AQ_TERN_TTQ || !segs[i].Wt || segs[i].codes, -EINVAL, "aq_tern_fwd: layer %d: TWN decodes Wt from codes: pass both", i);
+        decode = decode || (mode == AQ_TERN_TWN && segs[i].Wt);
+    }
+    const size_t need = tern_ws_bytes(segs, nseg);
+    AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
+               "aq_tern_fwd: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
+    TernTab tab;
+    const int blocks = tern_table(segs, nseg, workspace, tab);
+    AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_fwd: too many elements for one launch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tern_absstat_kernel, dim3(blocks), dim3(256), 0, st, tab);
+    hipLaunchKernelGGL(tern_delta_kernel, dim3(nseg), dim3(256), 0, st, tab, factor, threshold_from_max ? 1 : 0);
+    if (mode == AQ_TERN_TTQ) {
+        hipLaunchKernelGGL(tern_emit_kernel<true>, dim3(blocks), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(tern_codebook_kernel<true>, dim3(nseg), dim3(256), 0, st, tab);
+    } else {
+        hipLaunchKernelGGL(tern_emit_kernel<false>, dim3(blocks), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(tern_codebook_kernel<false>, dim3(nseg), dim3(256), 0, st, tab);
+        if (decode) hipLaunchKernelGGL(tern_decode_kernel, dim3(blocks), dim3(256), 0, st, tab);
+    }
+    return check_launch("aq_tern_fwd");
+}
+
+int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace aq;
+    if (int rc = tern_validate("aq_tern_bwd", segs, nseg)) return rc;
+    AQ_REQUIRE(mode == AQ_TERN_TWN || mode == AQ_TERN_TTQ || mode == AQ_TERN_INQ, -EINVAL, "aq_tern_bwd: mode %d", mode);
+    for (int i = 0; i < nseg; ++i) {
+        AQ_REQUIRE(segs[i].dWt && segs[i].dW, -EFAULT, "aq_tern_bwd: layer %d: dWt / dW is NULL", i);
+        AQ_REQUIRE(mode != AQ_TERN_TTQ || (segs[i].Wp && segs[i].Wn && segs[i].stats), -EFAULT, "aq_tern_bwd: layer %d: TTQ needs Wp, Wn and stats", i);
+        AQ_REQUIRE(mode != AQ_TERN_INQ || segs[i].mask, -EFAULT, "aq_tern_bwd: layer %d: INQ needs the partition mask", i);
+    }
+    const size_t need = tern_ws_bytes(segs, nseg);
+    AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
+               "aq_tern_bwd: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
+    TernTab tab;
+    const int blocks = tern_table(segs, nseg, workspace, tab);
+    AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_bwd: too many elements for one launch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == AQ_TERN_TTQ) {
+        hipLaunchKernelGGL(tern_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(tern_scale_grad_kernel, dim3(nseg), dim3(256), 0, st, tab);
+    } else if (mode == AQ_TERN_INQ) {
+        hipLaunchKernelGGL(tern_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, tab);
+    } else {
+        hipLaunchKernelGGL(tern_bwd_kernel<0>, dim3(blocks), dim3(256), 0, st, tab);
+    }
+    return check_launch("aq_tern_bwd");
+}
+
+int aq_inq_partition(float *W, uint8_t *mask, uint8_t *codes, long long n, float tau, int n1, int n2, void *stream)
+{
+    using namespace aq;
+    AQ_REQUIRE(n >= 0 && n < (1LL << 38), -EINVAL, "aq_inq_partition: bad element count");
+    if (n == 0) return 0;
+    AQ_REQUIRE(W && mask, -EFAULT, "aq_inq_partition: NULL pointer");
+    AQ_REQUIRE(n1 >= n2 && n1 <= 126 && n2 >= -125 && n1 - n2 < 120, -EDOM, "aq_inq_partition: exponent range [%d, %d]", n2, n1);
+    AQ_REQUIRE(tau >= 0.0f, -EDOM, "aq_inq_partition: negative threshold");
+    hipLaunchKernelGGL(inq_partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), W, mask, codes, n, tau,
+                       n1, n2);
+    return check_launch("aq_inq_partition");
+}
+
+} // extern "C"

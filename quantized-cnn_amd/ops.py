@@ -622,3 +622,94 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, betas=(0.9, 0.999
         arr[i].n = p.numel()
         arr[i].reg = float(regs[i]) if regs is not None else 0.0
     _lib.check(_lib.lib().aq_adam_step(arr, n, float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream()))
+
+
+# ------------------------------------------------------ ternary / power-of-two quantisers (TWN, TTQ, INQ)
+
+_TERN_MODES = {"twn": _lib.TERN_TWN, "ttq": _lib.TERN_TTQ, "inq": _lib.TERN_INQ}
+
+
+def tern_forward(ws, mode="twn", factor=0.7, threshold_from_max=False, Wp=None, Wn=None, codes=True, packed=False, decoded=True):
+    """Ternary quantisation of a list of weight tensors in one call (five small launches for all of them):
+    delta = factor * mean|w| (threshold_from_max: factor * max|w|); code 1 where w > delta, 2 where w < -delta, else 0.
+    mode "twn": both scales = mean of |w| above delta; "ttq": scales are the learned Wp[i], Wn[i] (one-element tensors).
+    Returns one dict per tensor: "codes" uint8 (shape of w), "packed" uint8 bytes (2 bits per code), "Wt" = q[codes],
+    "stats" fp32 [4] = (delta, positive scale, negative scale, number of non-zero codes), "q" fp32 [3] = (0, +pos, -neg).
+    At most 32 tensors per call."""
+    n = len(ws)
+    if mode not in ("twn", "ttq"):
+        raise ValueError("tern_forward: mode %r (twn or ttq)" % (mode,))
+    if mode == "ttq" and (Wp is None or Wn is None or len(Wp) != n or len(Wn) != n):
+        raise ValueError("tern_forward: mode ttq needs one Wp and one Wn per tensor")
+    if mode == "twn" and decoded and not codes:
+        raise ValueError("tern_forward: TWN decodes Wt from the codes; ask for both")
+    out = []
+    for base in range(0, n, 32):
+        chunk = ws[base:base + 32]
+        segs = (_lib.AqTernSeg * len(chunk))()
+        dev = chunk[0].device
+        aux = torch.empty((len(chunk), 8), dtype=torch.float32, device=dev)  # [stats(4) | q(3) | pad]
+        for i, w in enumerate(chunk):
+            d = {"stats": aux[i, :4], "q": aux[i, 4:7]}
+            segs[i].W, segs[i].n = _lib.ptr(w, name="w[%d]" % (base + i)), w.numel()
+            segs[i].stats, segs[i].q = aux.data_ptr() + 32 * i, aux.data_ptr() + 32 * i + 16
+            if codes:
+                d["codes"] = torch.empty(w.shape, dtype=torch.uint8, device=dev)
+                segs[i].codes = d["codes"].data_ptr()
+            if packed:
+                d["packed"] = torch.empty((w.numel() + 3) // 4, dtype=torch.uint8, device=dev)
+                segs[i].packed = d["packed"].data_ptr()
+            if decoded:
+                d["Wt"] = torch.empty(w.shape, dtype=torch.float32, device=dev)
+                segs[i].Wt = d["Wt"].data_ptr()
+            if mode == "ttq":
+                segs[i].Wp = _lib.ptr(Wp[base + i], name="Wp")
+                segs[i].Wn = _lib.ptr(Wn[base + i], name="Wn")
+            out.append(d)
+        nbytes = _lib.lib().aq_tern_workspace_bytes(segs, len(chunk))
+        wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().aq_tern_fwd(segs, len(chunk), _TERN_MODES[mode], float(factor), int(bool(threshold_from_max)), wsb.data_ptr(),
+                                          nbytes, _lib.stream()))
+    return out
+
+
+def tern_backward(ws, dWts, mode, stats=None, Wp=None, Wn=None, masks=None):
+    """Gradients of the latent weights from d loss / d (quantized weights): "twn" straight through; "ttq" scaled by
+    region (stats[i] as tern_forward left it gives delta) plus (dWp[i], dWn[i]); "inq" masked by masks[i] (uint8,
+    1 = trainable).  -> (dW list, dWp list | None, dWn list | None)."""
+    n = len(ws)
+    dWs, dps, dns = [], ([] if mode == "ttq" else None), ([] if mode == "ttq" else None)
+    for base in range(0, n, 32):
+        chunk = ws[base:base + 32]
+        segs = (_lib.AqTernSeg * len(chunk))()
+        dev = chunk[0].device
+        sg = torch.empty((len(chunk), 2), dtype=torch.float32, device=dev) if mode == "ttq" else None
+        for i, w in enumerate(chunk):
+            g = dWts[base + i]
+            if g.numel() != w.numel():
+                raise ValueError("tern_backward: gradient %d has %d elements, the weight %d" % (base + i, g.numel(), w.numel()))
+            dw = torch.empty_like(w)
+            dWs.append(dw)
+            segs[i].W, segs[i].n = _lib.ptr(w, name="w"), w.numel()
+            segs[i].dWt, segs[i].dW = _lib.ptr(g, name="dWt"), _lib.ptr(dw)
+            if mode == "ttq":
+                segs[i].stats = _lib.ptr(stats[base + i], name="stats")
+                segs[i].Wp, segs[i].Wn = _lib.ptr(Wp[base + i], name="Wp"), _lib.ptr(Wn[base + i], name="Wn")
+                segs[i].dWp, segs[i].dWn = sg.data_ptr() + 8 * i, sg.data_ptr() + 8 * i + 4
+                dps.append(sg[i, 0])
+                dns.append(sg[i, 1])
+            if mode == "inq":
+                segs[i].mask = _lib.ptr(masks[base + i], torch.uint8, "mask")
+        nbytes = _lib.lib().aq_tern_workspace_bytes(segs, len(chunk))
+        wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().aq_tern_bwd(segs, len(chunk), _TERN_MODES[mode], wsb.data_ptr(), nbytes, _lib.stream()))
+    return dWs, dps, dns
+
+
+def inq_partition(w, mask, tau, n1, n2, codes=None):
+    """One INQ partition step in place on w (fp32) and mask (uint8): trainable weights with |w| >= tau are rounded
+    to {0, +-2^n2 .. +-2^n1} and frozen; codes (uint8, optional) receives the level codes (255 = still trainable)."""
+    if mask.shape != w.shape or (codes is not None and codes.shape != w.shape):
+        raise ValueError("inq_partition: mask / codes must have the shape of w")
+    _lib.check(_lib.lib().aq_inq_partition(_lib.ptr(w, name="w"), _lib.ptr(mask, torch.uint8, "mask"), _lib.ptr(codes, torch.uint8, "codes"),
+                                           w.numel(), float(tau), int(n1), int(n2), _lib.stream()))

@@ -1,0 +1,322 @@
+"""Ternary (TWN, TTQ) and incremental power-of-two (INQ) quantized layers behind the module API of the
+adaptive-quantisation variants: the methods the reference's README cites (README.md:3-29) next to its own soft
+level assignment.  The reference's scripts implement none of them, so nothing here can be compared with
+reference code: the arithmetic follows the papers (Li, Zhang, Liu 2016; Zhu, Han, Mao, Dally 2017; Zhou et al.
+2017) and is checked against a CPU restatement written from the same papers - parity unpinned.
+
+    mode_q = "twn" : w~ = alpha * sign(w) above delta = 0.7 * mean|w|, alpha = mean of |w| above delta; straight-through
+    mode_q = "ttq" : w~ = +Wp / -Wn above / below +-delta with learned Wp, Wn; scaled straight-through gradients
+    mode_q = "inq" : full-precision weights whose largest-magnitude share is frozen at powers of two, stage by stage
+
+Forward convolutions read the 1-byte codes and a three-entry codebook and decode them while the weight tile is
+staged into LDS (the scale rides in the codebook); the backward pass uses the decoded weights.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import layers, ops
+from .layers import model_loss  # noqa: F401  (l2 on every "weight" parameter, adp_qtz_fan.py:737-743)
+
+beta = 1  # unused by these layers; present so that train.TrainStep can treat this module like a variant module
+
+
+class _TernConv(torch.autograd.Function):
+    """y = conv(x, w~): forward from codes + codebook, backward through the decoded w~ and the quantiser's
+    straight-through rule.  q: pre-computed dict of ops.tern_forward for this weight (or None)."""
+
+    @staticmethod
+    def forward(ctx, x, w, Wp, Wn, layer, q):
+        x = x.contiguous()
+        if q is None:
+            q = layer.quantize()
+        ctx.layer, ctx.q = layer, q
+        ctx.save_for_backward(x, w, Wp, Wn)
+        return ops.conv_forward_codes(x, q["codes"], q["q"], layer.stride, layer.padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, Wp, Wn = ctx.saved_tensors
+        L, q = ctx.layer, ctx.q
+        dy = dy.contiguous()
+        dx = ops.conv_dgrad(dy, q["Wt"], x.shape, L.stride, pad=L.padding) if ctx.needs_input_grad[0] else None
+        dWt = ops.conv_wgrad(x, dy, L.stride, ks=L.ksize, pad=L.padding)
+        if L.mode_q == "ttq":
+            dW, dp, dn = ops.tern_backward([w], [dWt], "ttq", stats=[q["stats"]], Wp=[Wp], Wn=[Wn])
+            return dx, dW[0], dp[0].reshape(Wp.shape), dn[0].reshape(Wn.shape), None, None
+        dW, _, _ = ops.tern_backward([w], [dWt], "twn")
+        return dx, dW[0], None, None, None, None
+
+
+class _TernLinear(torch.autograd.Function):
+    """y = x @ w~ + bias with w (in, out) like the reference's MyLinear (adp_qtz_fan.py:646-647)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, Wp, Wn, layer, q):
+        x = x.contiguous()
+        if q is None:
+            q = layer.quantize()
+        ctx.layer, ctx.q = layer, q
+        ctx.save_for_backward(x, w, Wp, Wn)
+        return ops.linear_forward(x, q["Wt"], bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, Wp, Wn = ctx.saved_tensors
+        L, q = ctx.layer, ctx.q
+        dx, dWt, db = ops.linear_backward(x, q["Wt"], dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        if L.mode_q == "ttq":
+            dW, dp, dn = ops.tern_backward([w], [dWt], "ttq", stats=[q["stats"]], Wp=[Wp], Wn=[Wn])
+            return dx, dW[0], db, dp[0].reshape(Wp.shape), dn[0].reshape(Wn.shape), None, None
+        dW, _, _ = ops.tern_backward([w], [dWt], "twn")
+        return dx, dW[0], db, None, None, None, None
+
+
+class _TernBase(nn.Module):
+    def _setup_quantizer(self, mode_q, factor, threshold_from_max):
+        if mode_q not in ("twn", "ttq"):
+            raise ValueError("mode_q must be 'twn' or 'ttq' (got %r)" % (mode_q,))
+        self.mode_q, self.factor, self.threshold_from_max = mode_q, float(factor), bool(threshold_from_max)
+        self._shared = None
+        with torch.no_grad():
+            a = self.weight.abs()
+            delta = self.factor * (a.max() if self.threshold_from_max else a.mean())
+            big = a[a > delta]
+            init = float(big.mean()) if big.numel() else float(a.mean())
+        if mode_q == "ttq":  # learned scales start at TWN's alpha (Zhu et al. 2017 initialise from the pretrained weights)
+            self.Wp = nn.Parameter(torch.full((1,), init))
+            self.Wn = nn.Parameter(torch.full((1,), init))
+        else:
+            self.register_parameter("Wp", None)
+            self.register_parameter("Wn", None)
+
+    def quantize(self, packed=False):
+        """-> dict of ops.tern_forward for this layer's weight (codes, Wt, stats, q[, packed])."""
+        if self._shared is not None and not packed:
+            q, self._shared = self._shared, None
+            return q
+        w = self.weight.detach()
+        if self.mode_q == "ttq":
+            return ops.tern_forward([w], "ttq", self.factor, self.threshold_from_max, [self.Wp.detach()], [self.Wn.detach()], packed=packed)[0]
+        return ops.tern_forward([w], "twn", self.factor, self.threshold_from_max, packed=packed)[0]
+
+
+class TernaryConv2d(_TernBase):
+    def __init__(self, in_channel, out_channel, ksize=3, stride=1, padding=1, mode_q="twn", factor=0.7, threshold_from_max=False):
+        super().__init__()
+        self.ksize, self.stride, self.padding = ksize, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channel, in_channel, ksize, ksize))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self._setup_quantizer(mode_q, factor, threshold_from_max)
+
+    def forward(self, x, res=None, bn=None, split=False):
+        """Same call convention as layers.QConv2d.forward (res added to the output, bn applied to the input, split
+        returns the raw input or its pooled shortcut next to the output)."""
+        xs = x
+        if bn is not None:
+            if split:
+                z, xs = layers.bn_relu(bn, x, split=True)
+            else:
+                z = layers.bn_relu(bn, x)
+        else:
+            z = x
+        y = _TernConv.apply(z, self.weight, self.Wp, self.Wn, self, None)
+        if res is not None:
+            y = y + res
+        if isinstance(split, tuple):
+            return y, layers._Shortcut.apply(xs, *split)
+        return (y, xs) if split else y
+
+
+class TernaryLinear(_TernBase):
+    def __init__(self, in_feature, out_feature, mode_q="twn", factor=0.7, threshold_from_max=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(in_feature, out_feature))
+        bound = 1 / math.sqrt(in_feature)
+        nn.init.uniform_(self.weight, -bound * math.sqrt(3.0), bound * math.sqrt(3.0))
+        self.bias = nn.Parameter(torch.empty(out_feature).uniform_(-bound, bound))
+        self._setup_quantizer(mode_q, factor, threshold_from_max)
+
+    def forward(self, x):
+        return _TernLinear.apply(x, self.weight, self.bias, self.Wp, self.Wn, self, None)
+
+
+class _InqMask(torch.autograd.Function):
+    """Effective weight of an INQ layer: the parameter where it is still trainable, the frozen level elsewhere; the
+    gradient of frozen weights is zeroed (Zhou et al. 2017, eq. 8).  Taking the frozen values from the codes rather
+    than from the parameter keeps them fixed under optimizers that move a coordinate without a gradient (momentum,
+    Adam's running averages)."""
+
+    @staticmethod
+    def forward(ctx, w, mask, frozen):
+        ctx.save_for_backward(w, mask)
+        return w.view_as(w) if frozen is None else torch.where(mask.bool(), w, frozen)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, mask = ctx.saved_tensors
+        dW, _, _ = ops.tern_backward([w.detach()], [g.contiguous()], "inq", masks=[mask])
+        return dW[0], None, None
+
+
+class INQConv2d(nn.Module):
+    """Convolution whose weights are frozen at powers of two stage by stage: quantize_portion(0.5), (0.75), (0.875),
+    (1.0) between retraining phases.  `mask` (1 = still trainable) and `codes` (level codes of the frozen weights, 5 bits
+    for bits=5) are buffers, so they travel with the state_dict."""
+
+    def __init__(self, in_channel, out_channel, ksize=3, stride=1, padding=1, bits=5):
+        super().__init__()
+        self.ksize, self.stride, self.padding, self.bits = ksize, stride, padding, bits
+        self.weight = nn.Parameter(torch.empty(out_channel, in_channel, ksize, ksize))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self.register_buffer("mask", torch.ones(self.weight.shape, dtype=torch.uint8))
+        self.register_buffer("codes", torch.full(self.weight.shape, 255, dtype=torch.uint8))
+        self.register_buffer("exponents", torch.zeros(2, dtype=torch.int32))  # (n1, n2), fixed at the first stage
+        self._have_exp = False
+
+    def quantize_portion(self, fraction):
+        """Freeze the largest-magnitude weights until `fraction` of all weights are frozen."""
+        w = self.weight.data
+        n = w.numel()
+        if not self._have_exp:
+            s = float(ops.absmax([w.contiguous()])[0]) if w.is_cuda else float(w.abs().max())
+            n1 = int(math.floor(math.log2(4.0 * s / 3.0)))
+            self.exponents.copy_(torch.tensor([n1, n1 + 1 - (2 ** (self.bits - 1)) // 2], dtype=torch.int32))
+            self._have_exp = True
+        frozen = n - int(self.mask.sum())
+        if frozen:
+            w.copy_(self.effective_weight().detach())  # drop whatever drift the optimizer left under the mask
+        k = int(round(float(fraction) * n)) - frozen
+        if k <= 0:
+            return 0
+        free = w.abs()[self.mask.bool()]
+        tau = float(torch.topk(free, min(k, free.numel()), largest=True, sorted=True).values[-1])
+        n1, n2 = (int(v) for v in self.exponents.tolist())
+        ops.inq_partition(w, self.mask, tau, n1, n2, self.codes)
+        self._q = None
+        return k
+
+    def effective_weight(self):
+        """The weights the layer computes with: trainable entries from the parameter, frozen ones from their codes."""
+        if not self._have_exp:
+            return _InqMask.apply(self.weight, self.mask, None)
+        if getattr(self, "_q", None) is None or self._q.device != self.weight.device:
+            self._q = self.codebook()
+        frozen = self._q[self.codes.clamp(max=self._q.numel() - 1).long()]
+        return _InqMask.apply(self.weight, self.mask, frozen)
+
+    def codebook(self):
+        """Level table of `codes`: index 0 = 0, 1 + 2 * (k - n2) + s = (-1)^s * 2^k."""
+        n1, n2 = (int(v) for v in self.exponents.tolist())
+        q = [0.0]
+        for k in range(n2, n1 + 1):
+            q += [2.0 ** k, -(2.0 ** k)]
+        return torch.tensor(q, dtype=torch.float32, device=self.weight.device)
+
+    def forward(self, x, res=None, bn=None, split=False):
+        xs = x
+        if bn is not None:
+            if split:
+                z, xs = layers.bn_relu(bn, x, split=True)
+            else:
+                z = layers.bn_relu(bn, x)
+        else:
+            z = x
+        y = layers.conv3x3(z, self.effective_weight(), self.stride, None, res, pad=self.padding)
+        if isinstance(split, tuple):
+            return y, layers._Shortcut.apply(xs, *split)
+        return (y, xs) if split else y
+
+    def forward_codes(self, x):
+        """Inference from the codes alone once every weight is frozen (decoded inside the convolution kernel)."""
+        if int(self.mask.sum()) != 0:
+            raise RuntimeError("forward_codes: %d weights are still trainable" % int(self.mask.sum()))
+        return ops.conv_forward_codes(x.contiguous(), self.codes, self.codebook(), self.stride, self.padding)
+
+
+def make_conv(config, in_channel, out_channel, ksize=3, stride=1, padding=1):
+    """Convolution of the flavour config.mode_q names ("twn" | "ttq" | "inq")."""
+    mode_q = getattr(config, "mode_q", "twn")
+    if mode_q == "inq":
+        return INQConv2d(in_channel, out_channel, ksize, stride, padding, bits=getattr(config, "inq_bits", 5))
+    return TernaryConv2d(in_channel, out_channel, ksize, stride, padding, mode_q, getattr(config, "tern_factor", 0.7),
+                         getattr(config, "tern_threshold_from_max", False))
+
+
+class Residual(layers._Block):
+    def __init__(self, config, in_channel, increase_dim):
+        super().__init__()
+        out_channel, stride = (in_channel * 2, 2) if increase_dim else (in_channel, 1)
+        self.bn1 = nn.BatchNorm2d(in_channel)
+        self.conv1 = make_conv(config, in_channel, out_channel, 3, stride, 1)
+        self.bn2 = nn.BatchNorm2d(out_channel)
+        self.conv2 = make_conv(config, out_channel, out_channel, 3, 1, 1)
+        self.shortcut = self._shortcut(in_channel, increase_dim)
+
+    def forward(self, x):
+        return self._residual_forward(x)
+
+
+class PreResidual(layers._Block):
+    def __init__(self, config, in_channel, increase_dim=False):
+        super().__init__()
+        self.conv1 = make_conv(config, in_channel, in_channel, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(in_channel)
+        self.conv2 = make_conv(config, in_channel, in_channel, 3, 1, 1)
+
+    def forward(self, x):
+        return self._preresidual_forward(x)
+
+
+class ResNet(nn.Module):
+    """The reference's ResNet-20 graph (adp_qtz_fan.py:696-734: full-precision conv0, 3 stages of n blocks, pre-activation,
+    pooled zero-padded shortcuts) with ternary / INQ convolutions in place of the adaptive ones."""
+
+    def __init__(self, config, n=3):
+        super().__init__()
+        self.conv0 = nn.Conv2d(3, 16, 3, 1, 1, bias=False)
+        self.bn0 = nn.BatchNorm2d(16)
+
+        def stage(in_plane, first):
+            blocks = [PreResidual(config, in_plane)] if first else [Residual(config, in_plane, True)]
+            width = in_plane if first else in_plane * 2
+            blocks += [Residual(config, width, False) for _ in range(n - 1)]
+            return nn.Sequential(*blocks)
+
+        self.layer1, self.layer2, self.layer3 = stage(16, True), stage(16, False), stage(32, False)
+        self.bnlast = nn.BatchNorm2d(64)
+        self.ap = nn.AvgPool2d(8)
+        mode_q = getattr(config, "mode_q", "twn")
+        self.linear = TernaryLinear(64, 10, mode_q if mode_q in ("twn", "ttq") else "twn") if mode_q != "inq" else nn.Linear(64, 10)
+
+    def quant_layers(self):
+        return [m for m in self.modules() if isinstance(m, _TernBase)]
+
+    def _quantize_all(self):
+        """One quantiser call for all ternary layers of the model (five launches) instead of one per layer."""
+        ls = self.quant_layers()
+        if not ls:
+            return
+        for mode in ("twn", "ttq"):
+            grp = [l for l in ls if l.mode_q == mode]
+            for key in {(l.factor, l.threshold_from_max) for l in grp}:
+                g = [l for l in grp if (l.factor, l.threshold_from_max) == key]
+                ws = [l.weight.detach() for l in g]
+                if mode == "ttq":
+                    qs = ops.tern_forward(ws, "ttq", key[0], key[1], [l.Wp.detach() for l in g], [l.Wn.detach() for l in g])
+                else:
+                    qs = ops.tern_forward(ws, "twn", key[0], key[1])
+                for l, q in zip(g, qs):
+                    l._shared = q
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
+        self._quantize_all()
+        c0 = self.conv0
+        out = layers.conv3x3(x, c0.weight, 1, None)
+        out = layers.bn_relu(self.bn0, out)
+        out = self.layer3(self.layer2(self.layer1(out)))
+        out = layers.bn_relu_pool(self.bnlast, self.ap, out)
+        return self.linear(out.view(out.size(0), -1))

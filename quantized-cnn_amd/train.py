@@ -38,9 +38,9 @@ def make_optimizers(model, config, capturable=False, fused=False):
     if fused:
         kw["fused"] = True
     # q_level of the `fix` variant has requires_grad=False: Adam skips parameters without grad
-    return (torch.optim.Adam(prim, lr=getattr(config, "prim_lr", 1e-2), **kw),
-            torch.optim.Adam(qlev, lr=getattr(config, "q_lr", 1e-3), **kw),
-            torch.optim.Adam(rest, lr=getattr(config, "lr", 1e-2), **kw))
+    groups = ((prim, getattr(config, "prim_lr", 1e-2)), (qlev, getattr(config, "q_lr", 1e-3)), (rest, getattr(config, "lr", 1e-2)))
+    # (models without adaptive layers, e.g. the ternary ones, have no p_c / q_level: only the groups that exist)
+    return tuple(torch.optim.Adam(g, lr=lr, **kw) for g, lr in groups if g)
 
 
 class DataParallel:

@@ -1,0 +1,209 @@
+"""Ternary (TWN, TTQ) and incremental power-of-two (INQ) quantisers against their CPU restatement.
+
+PARITY UNPINNED - no reference implementation: the reference repository cites these methods (README.md:3-29) and
+implements none of them, so the checker (oracle/aq_oracle.c: aqo_tern_*, aqo_inq_*) is itself written from the
+papers.  What the tests establish is that the HIP kernels compute what that restatement computes:
+codes, masks and rounded weights bit for bit when both sides use the same threshold; thresholds and scales
+(fp32 fixed-order sums against float64) at rel 2e-6 / 1e-5; masked gradient sums at 2e-5 of their scale.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import quantized_cnn_amd.ops as ops
+    import quantized_cnn_amd.ternary as T
+DEV = "cuda"
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 16, 17, 255, 2048, 2049, 36864, 1_000_003])
+@pytest.mark.parametrize("mode,from_max,factor", [("twn", False, 0.7), ("ttq", True, 0.05), ("ttq", False, 0.7)])
+def test_ternary_forward_vs_oracle(n, mode, from_max, factor):
+    rs = np.random.RandomState(n % 9973 + int(factor * 100))
+    w = (rs.standard_normal(n) * 0.05).astype(np.float32)
+    Wp, Wn = np.float32(0.11), np.float32(0.07)
+    kw = dict(Wp=[cu([Wp])], Wn=[cu([Wn])]) if mode == "ttq" else {}
+    out = ops.tern_forward([cu(w)], mode, factor, from_max, packed=True, **kw)[0]
+    stats, q = out["stats"].cpu().numpy(), out["q"].cpu().numpy()
+    ref = O.tern_forward(w, mode, factor, from_max, Wp, Wn)
+    assert abs(stats[0] - ref["delta"]) <= 2e-6 * ref["delta"] + 1e-30
+    # codes: bit-exact for the kernel's own threshold ...
+    same = O.tern_codes(w, stats[0])
+    codes = out["codes"].cpu().numpy()
+    assert np.array_equal(codes, same["codes"])
+    # ... and against the oracle's threshold wherever |w| is not within rounding of it
+    far = np.abs(np.abs(w) - ref["delta"]) > 4e-6 * ref["delta"]
+    assert np.array_equal(codes[far], ref["codes"][far])
+    assert np.array_equal(out["packed"].cpu().numpy(), O.pack_codes(codes, 2))
+    assert stats[3] == same["npos"] + same["nneg"]
+    if mode == "ttq":
+        assert stats[1] == Wp and stats[2] == Wn
+    else:
+        alpha = same["sum_abs"] / max(same["npos"] + same["nneg"], 1)
+        assert abs(stats[1] - alpha) <= 1e-5 * alpha + 1e-30 and stats[1] == stats[2]
+    assert q[0] == 0.0 and q[1] == stats[1] and q[2] == -stats[2]
+    assert np.array_equal(out["Wt"].cpu().numpy(), q[codes])
+
+
+def test_ternary_forward_many_layers_one_call_and_determinism():
+    rs = np.random.RandomState(1)
+    shapes = [(16, 16, 3, 3)] * 6 + [(32, 16, 3, 3)] + [(32, 32, 3, 3)] * 5 + [(64, 32, 3, 3)] + [(64, 64, 3, 3)] * 5 + [(64, 10)]
+    shapes = shapes * 2  # 38 tensors: more than one call's worth of 32
+    ws = [cu(rs.standard_normal(s) * (0.02 + 0.01 * i)) for i, s in enumerate(shapes)]
+    a = ops.tern_forward(ws, "twn")
+    b = ops.tern_forward(ws, "twn")
+    for w, x, y in zip(ws, a, b):
+        assert torch.equal(x["codes"], y["codes"]) and torch.equal(x["stats"], y["stats"]) and torch.equal(x["Wt"], y["Wt"])
+        ref = O.tern_forward(w.cpu().numpy(), "twn")
+        assert abs(float(x["stats"][0]) - ref["delta"]) <= 2e-6 * ref["delta"]
+        assert x["codes"].shape == w.shape
+        same = O.tern_codes(w.cpu().numpy(), x["stats"][0].item())
+        assert np.array_equal(x["codes"].cpu().numpy(), same["codes"])
+    # edge cases: all zeros (no code fires, alpha 0), constants
+    z = ops.tern_forward([torch.zeros(100, device=DEV), torch.full((7,), 0.5, device=DEV)], "twn")
+    assert int(z[0]["codes"].sum()) == 0 and float(z[0]["stats"][1]) == 0.0 and float(z[0]["stats"][3]) == 0.0
+    assert int(z[1]["codes"].min()) == 1 and abs(float(z[1]["stats"][1]) - 0.5) < 1e-7  # 0.5 > 0.7 * 0.5
+    with pytest.raises(ValueError):
+        ops.tern_forward(ws[:1], "ttq")
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048, 70001])
+def test_ternary_backward_vs_oracle(n):
+    rs = np.random.RandomState(n)
+    w = (rs.standard_normal(n) * 0.05).astype(np.float32)
+    g = rs.standard_normal(n).astype(np.float32)
+    wd, gd = cu(w), cu(g)
+    # TWN: straight through
+    dW, _, _ = ops.tern_backward([wd], [gd], "twn")
+    assert torch.equal(dW[0], gd)
+    # TTQ
+    Wp, Wn = np.float32(0.13), np.float32(0.09)
+    fw = ops.tern_forward([wd], "ttq", 0.05, True, [cu([Wp])], [cu([Wn])])[0]
+    delta = float(fw["stats"][0])
+    dW, dp, dn = ops.tern_backward([wd], [gd], "ttq", stats=[fw["stats"]], Wp=[cu([Wp])], Wn=[cu([Wn])])
+    dw_ref, dp_ref, dn_ref = O.tern_backward(w, g, "ttq", delta, Wp, Wn)
+    assert np.array_equal(dW[0].cpu().numpy().view(np.uint32), dw_ref.view(np.uint32))
+    scale = np.abs(g).sum()
+    assert abs(float(dp[0]) - dp_ref) <= 2e-5 * scale and abs(float(dn[0]) - dn_ref) <= 2e-5 * scale
+    # the same scale gradients from autograd of the forward formula
+    wt_, gt_ = torch.from_numpy(w).double(), torch.from_numpy(g).double()
+    p, q = torch.tensor(float(Wp), dtype=torch.double, requires_grad=True), torch.tensor(float(Wn), dtype=torch.double, requires_grad=True)
+    wq = p * (wt_ > delta) - q * (wt_ < -delta)
+    (wq * gt_).sum().backward()
+    assert abs(dp_ref - float(p.grad)) <= 1e-9 * scale and abs(dn_ref - float(q.grad)) <= 1e-9 * scale
+    # INQ mask
+    mask = (rs.random_sample(n) < 0.4).astype(np.uint8)
+    dW, _, _ = ops.tern_backward([wd], [gd], "inq", masks=[cu(mask, torch.uint8)])
+    assert np.array_equal(dW[0].cpu().numpy(), np.where(mask != 0, g, np.float32(0.0)))
+
+
+def test_inq_partition_vs_oracle_stage_by_stage():
+    rs = np.random.RandomState(5)
+    n = 50_001
+    w = (rs.standard_normal(n) * 0.08).astype(np.float32)
+    n1, n2 = O.inq_exponents(np.abs(w).max(), 5)
+    assert n1 - n2 == 7
+    # decision boundaries of the level rule, zero, a subnormal, values above 1.5 * 2^n1 and below 2^(n2-1)
+    edge = []
+    for k in range(n2 - 2, n1 + 2):
+        for m in (0.5, 0.75, 1.0, 1.5):
+            v = np.float32(m * 2.0 ** k)
+            edge += [v, np.nextafter(v, np.float32(0)), np.nextafter(v, np.float32(4)), -v]
+    edge += [0.0, -0.0, 1e-41, 3.0 * 2.0 ** n1]
+    w[: len(edge)] = np.array(edge, np.float32)
+    wd = cu(w)
+    md = torch.ones(n, dtype=torch.uint8, device=DEV)
+    cd = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
+    wo, mo = w.copy(), np.ones(n, np.uint8)
+    for frac in (0.5, 0.75, 0.875, 1.0):
+        free = np.abs(wo[mo == 1])
+        k = int(round(frac * n)) - int((mo == 0).sum())
+        tau = np.sort(free)[::-1][k - 1] if frac < 1.0 else 0.0
+        ops.inq_partition(wd, md, tau, n1, n2, cd)
+        wo, mo, co = O.inq_partition(wo, mo, tau, n1, n2)
+        assert np.array_equal(wd.cpu().numpy().view(np.uint32), wo.view(np.uint32)), frac
+        assert np.array_equal(md.cpu().numpy(), mo) and np.array_equal(cd.cpu().numpy(), co), frac
+    assert mo.sum() == 0
+    levels = np.unique(np.abs(wo))
+    assert set(levels) <= {0.0} | {2.0 ** k for k in range(n2, n1 + 1)}
+    assert co.max() <= 16 and len(np.unique(co)) == 17  # zero + 8 exponents x 2 signs: 5 bits
+    # codes decode to the weights
+    q = np.array([0.0] + [s * 2.0 ** k for k in range(n2, n1 + 1) for s in (1, -1)], np.float32)
+    assert np.array_equal(q[co], wo)
+
+
+@pytest.mark.parametrize("mode_q", ["twn", "ttq"])
+def test_ternary_conv_module_forward_and_gradients(mode_q):
+    torch.manual_seed(3)
+    conv = T.TernaryConv2d(8, 12, 3, 2, 1, mode_q).to(DEV)
+    x = torch.randn(4, 8, 10, 10, device=DEV, requires_grad=True)
+    y = conv(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    w = conv.weight.detach().cpu().numpy()
+    ref = O.tern_forward(w, mode_q, 0.7, False, *((float(conv.Wp.detach()), float(conv.Wn.detach())) if mode_q == "ttq" else (None, None)))
+    Wt = torch.from_numpy(ref["Wt"]).to(DEV)
+    xt = x.detach().clone().requires_grad_(True)
+    wt = Wt.clone().requires_grad_(True)
+    yt = torch.nn.functional.conv2d(xt, wt, stride=2, padding=1)
+    yt.backward(gy)
+    assert (y - yt).abs().max().item() <= 2e-5 * yt.abs().max().item()
+    assert (x.grad - xt.grad).abs().max().item() <= 2e-5 * xt.grad.abs().max().item()
+    dWt = wt.grad.cpu().numpy()
+    if mode_q == "twn":
+        assert np.abs(conv.weight.grad.cpu().numpy() - dWt).max() <= 2e-5 * np.abs(dWt).max()
+        assert conv.Wp is None
+    else:
+        dw_ref, dp_ref, dn_ref = O.tern_backward(w, dWt, "ttq", ref["delta"], ref["pos"], ref["neg"])
+        assert np.abs(conv.weight.grad.cpu().numpy() - dw_ref).max() <= 2e-5 * np.abs(dw_ref).max()
+        scale = np.abs(dWt).sum()
+        assert abs(float(conv.Wp.grad) - dp_ref) <= 2e-5 * scale and abs(float(conv.Wn.grad) - dn_ref) <= 2e-5 * scale
+
+
+def test_ternary_resnet20_trains_and_inq_stages():
+    from quantized_cnn_amd.train import TrainStep
+    torch.manual_seed(0)
+    c = argparse.Namespace(mode_q="ttq", l2_reg=5e-4, prim_lr=1e-2, q_lr=1e-3, lr=1e-3)
+    model = T.ResNet(c, 3).to(DEV).train()
+    x = torch.randn(16, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (16,), device=DEV)
+    step = TrainStep(model, c, T)
+    losses = [float(step(x, y)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    # INQ: stages freeze the right share, frozen weights are powers of two and stop moving
+    ci = argparse.Namespace(mode_q="inq", l2_reg=0.0, prim_lr=1e-2, q_lr=1e-3, lr=1e-2)
+    net = T.ResNet(ci, 1).to(DEV).train()
+    convs = [m for m in net.modules() if isinstance(m, T.INQConv2d)]
+    st = TrainStep(net, ci, T)
+    xb, yb = torch.randn(8, 3, 32, 32, device=DEV), torch.randint(0, 10, (8,), device=DEV)
+    for frac in (0.5, 0.75, 1.0):
+        for m in convs:
+            m.quantize_portion(frac)
+        frozen_before = [m.effective_weight().detach()[m.mask == 0].clone() for m in convs]
+        for m in convs:
+            share = 1.0 - float(m.mask.float().mean())
+            assert abs(share - frac) <= 2.0 / m.weight.numel() + 1e-3, (frac, share)
+        st(xb, yb)
+        torch.nn.functional.cross_entropy(net(xb), yb).backward()
+        for m, fb in zip(convs, frozen_before):
+            assert torch.equal(m.effective_weight().detach()[m.mask == 0], fb)  # frozen levels stay whatever the optimizer does
+            assert float(m.weight.grad[m.mask == 0].abs().max()) == 0.0         # and receive no gradient
+            assert frac == 1.0 or float(m.weight.grad[m.mask == 1].abs().max()) > 0.0
+            fz = m.effective_weight().detach()[m.mask == 0].abs()
+            nz = fz[fz > 0]
+            assert torch.equal(torch.log2(nz), torch.log2(nz).round())
+            m.weight.grad = None
+    m = convs[0]
+    xin = torch.randn(2, m.weight.shape[1], 12, 12, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(m.forward_codes(xin), m(xin)) or (m.forward_codes(xin) - m(xin)).abs().max().item() <= 1e-6

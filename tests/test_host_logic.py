@@ -79,3 +79,32 @@ def test_beta_schedule_follows_the_reference_loop():
             ref_beta, ref_lrs = _reference_loop_head(epoch, ref_beta, ref_lrs, bl, el)
             assert beta == ref_beta, (epoch, beta, ref_beta)
             assert [o.param_groups[0]["lr"] for o in opts] == ref_lrs, epoch
+
+
+def test_ternary_and_inq_oracle_known_answers():
+    """The CPU restatement of TWN / TTQ / INQ (parity unpinned: written from the cited papers, no reference code)
+    on hand-computed cases."""
+    from oracle import oracle as O
+    w = np.array([0.5, -0.1, 0.05, -0.6, 0.0, 0.3], np.float32)
+    r = O.tern_forward(w, "twn")                     # mean|w| = 1.55 / 6, delta = 0.7 * that = 0.18083
+    assert abs(r["delta"] - 0.7 * 1.55 / 6) < 1e-7
+    assert list(r["codes"]) == [1, 0, 0, 2, 0, 1]
+    assert abs(r["pos"] - (0.5 + 0.6 + 0.3) / 3) < 1e-7 and r["pos"] == r["neg"]
+    assert np.allclose(r["Wt"], np.array([1, 0, 0, -1, 0, 1]) * r["pos"])
+    t = O.tern_forward(w, "ttq", 0.05, True, 0.7, 0.2)   # delta = 0.05 * max|w| = 0.03
+    assert list(t["codes"]) == [1, 2, 1, 2, 0, 1] and np.allclose(t["Wt"], [0.7, -0.2, 0.7, -0.2, 0, 0.7])
+    g = np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], np.float32)
+    dw, dp, dn = O.tern_backward(w, g, "ttq", t["delta"], 0.7, 0.2)
+    assert dp == 1 + 3 + 6 and dn == -(2 + 4)
+    assert np.allclose(dw, [0.7, 0.4, 2.1, 0.8, 5.0, 4.2])
+    # INQ, 5 bits, max|w| = 0.6: n1 = floor(log2(0.8)) = -1, n2 = n1 - 7 = -8
+    n1, n2 = O.inq_exponents(0.6, 5)
+    assert (n1, n2) == (-1, -8)
+    v = np.array([0.6, 0.374, 0.375, -0.2, 0.0029, 0.0019, 0.0, -0.74, 0.75], np.float32)
+    q, m, c = O.inq_partition(v, np.ones(9, np.uint8), 0.0, n1, n2)
+    #  0.6 -> 0.5 (in [0.375, 0.75)); 0.374 -> 0.25; 0.375 -> 0.5; -0.2 -> -0.25 (in [0.1875, 0.375));
+    #  0.0029 -> 2^-8 (in [2^-9, 1.5 * 2^-8)); 0.0019 -> 0 (< 2^-9 = 0.00195); 0.75 -> clamps to 2^n1 = 0.5
+    assert list(q) == [0.5, 0.25, 0.5, -0.25, 2.0 ** -8, 0.0, 0.0, -0.5, 0.5]
+    assert m.sum() == 0 and list(c) == [15, 13, 15, 14, 1, 0, 0, 16, 15]
+    q2, m2, c2 = O.inq_partition(v, np.ones(9, np.uint8), 0.37, n1, n2)   # only magnitudes >= 0.37 join
+    assert list(m2) == [0, 0, 0, 1, 1, 1, 1, 0, 0] and q2[3] == np.float32(-0.2) and c2[3] == 255
