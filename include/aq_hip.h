@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 8
+#define AQ_ABI_VERSION 9
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -377,6 +377,19 @@ int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, si
  * 1 + 2 * (k - n2) + (w < 0) for +-2^k.  The caller derives tau from the magnitude quantile of the stage and
  * n1 = floor(log2(4 * max|w| / 3)), n2 = n1 + 1 - 2^(bits-1) / 2 once, before the first stage. */
 int aq_inq_partition(float *W, uint8_t *mask, uint8_t *codes, long long n, float tau, int n1, int n2, void *stream);
+
+/* ---- Probabilistic Knowledge Transfer loss (Passalis & Tefas 2018, cited at README.md:24-29) ----------------------
+ * No counterpart in the reference's scripts (adp_qtz_hint.py:301-318 trains without a teacher pass): restated from the
+ * published method, parity unpinned.  student [N, Ds], teacher [N, Dt] feature matrices of one batch:
+ *   xh = x / (|x| + eps) per row;  K = (xh xh^T + 1) / 2  (N x N, on the fp32 matrix cores);  P_ij = K_ij / sum_j K_ij;
+ *   loss[0] = mean_ij Pt_ij * log((Pt_ij + eps) / (Ps_ij + eps)).
+ * dstudent != NULL: also d loss / d student [N, Ds] (times grad_scale[0] when grad_scale != NULL, a device scalar); the
+ * teacher is a constant.  workspace: aq_pkt_workspace_bytes(N, Ds, Dt) bytes, 16-byte aligned. */
+size_t aq_pkt_workspace_bytes(int N, int Ds, int Dt);
+int aq_pkt_loss(const float *student, const float *teacher, int N, int Ds, int Dt, float eps, float *loss, const float *grad_scale,
+                float *dstudent, void *workspace, size_t workspace_bytes, void *stream);
+/* K = (xh xh^T + 1) / 2 alone.  workspace: ceil256(N * D * 4) + ceil256(N * 4) bytes. */
+int aq_pkt_kernel_matrix(const float *feat, int N, int D, float eps, float *K, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -352,3 +352,17 @@ def inq_partition(w, mask, tau, n1, n2):
     lib().aqo_inq_partition(a.ctypes.data_as(C.POINTER(C.c_float)), m.ctypes.data_as(u8), codes.ctypes.data_as(u8), a.size,
                             float(np.float32(tau)), int(n1), int(n2))
     return a, m, codes
+
+
+def pkt_loss(student, teacher, eps=1e-7):
+    """PKT divergence of Passalis & Tefas (2018) with the cosine kernel, float64: PARITY UNPINNED (no reference
+    implementation; restated from the published method): rows normalised by (|x| + eps), K = (xh xh^T + 1) / 2,
+    P = K / row sums, loss = mean(Pt * log((Pt + eps) / (Ps + eps)))."""
+    def cond(x):
+        x = np.asarray(x, np.float64)
+        xh = x / (np.sqrt((x ** 2).sum(axis=1, keepdims=True)) + eps)
+        xh[np.isnan(xh)] = 0.0
+        K = (xh @ xh.T + 1.0) / 2.0
+        return K / K.sum(axis=1, keepdims=True)
+    Ps, Pt = cond(student), cond(teacher)
+    return float(np.mean(Pt * np.log((Pt + eps) / (Ps + eps))))

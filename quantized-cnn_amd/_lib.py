@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -28,6 +28,7 @@ EXPORTS = (
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
     "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
     "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition",
+    "aq_pkt_workspace_bytes", "aq_pkt_loss", "aq_pkt_kernel_matrix",
 )
 TERN_TWN, TERN_TTQ, TERN_INQ = 0, 1, 2
 
@@ -143,6 +144,11 @@ def lib():
         L.aq_tern_bwd.argtypes = [C.POINTER(AqTernSeg), i, i, vp, sz, vp]
         L.aq_inq_partition.argtypes = [vp, vp, vp, C.c_longlong, f, i, i, vp]
         L.aq_tern_fwd.restype = L.aq_tern_bwd.restype = L.aq_inq_partition.restype = i
+        L.aq_pkt_workspace_bytes.argtypes = [i, i, i]
+        L.aq_pkt_workspace_bytes.restype = sz
+        L.aq_pkt_loss.argtypes = [vp, vp, i, i, i, f, vp, vp, vp, vp, sz, vp]
+        L.aq_pkt_kernel_matrix.argtypes = [vp, i, i, f, vp, vp, sz, vp]
+        L.aq_pkt_loss.restype = L.aq_pkt_kernel_matrix.restype = i
         L.aq_bn_workspace_bytes.argtypes = [i, i, i]
         L.aq_bn_workspace_bytes.restype = sz
         for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",

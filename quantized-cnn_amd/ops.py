@@ -713,3 +713,31 @@ def inq_partition(w, mask, tau, n1, n2, codes=None):
         raise ValueError("inq_partition: mask / codes must have the shape of w")
     _lib.check(_lib.lib().aq_inq_partition(_lib.ptr(w, name="w"), _lib.ptr(mask, torch.uint8, "mask"), _lib.ptr(codes, torch.uint8, "codes"),
                                            w.numel(), float(tau), int(n1), int(n2), _lib.stream()))
+
+
+# ------------------------------------------------------------- probabilistic knowledge transfer (PKT) loss
+
+def pkt_loss(student, teacher, eps=1e-7, need_grad=True, grad_scale=None):
+    """Cosine-kernel PKT divergence between the batch's student and teacher features (N, Ds) / (N, Dt):
+    -> (loss fp32 [1], d loss / d student or None).  grad_scale: optional one-element device tensor the gradient
+    is multiplied by."""
+    if student.dim() != 2 or teacher.dim() != 2 or student.shape[0] != teacher.shape[0]:
+        raise ValueError("pkt_loss: student %s / teacher %s must be (N, D) matrices of one batch" % (tuple(student.shape), tuple(teacher.shape)))
+    N, Ds, Dt = int(student.shape[0]), int(student.shape[1]), int(teacher.shape[1])
+    loss = torch.empty(1, dtype=torch.float32, device=student.device)
+    d = torch.empty_like(student) if need_grad else None
+    nbytes = _lib.lib().aq_pkt_workspace_bytes(N, Ds, Dt)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=student.device)
+    _lib.check(_lib.lib().aq_pkt_loss(_lib.ptr(student, name="student"), _lib.ptr(teacher, name="teacher"), N, Ds, Dt, float(eps), _lib.ptr(loss),
+                                      _lib.ptr(grad_scale, name="grad_scale"), _lib.ptr(d), ws.data_ptr(), nbytes, _lib.stream()))
+    return loss, d
+
+
+def pkt_kernel_matrix(feat, eps=1e-7):
+    """(cos(x_i, x_j) + 1) / 2 for all pairs of rows of feat (N, D) -> (N, N), on the fp32 matrix cores."""
+    N, D = int(feat.shape[0]), int(feat.shape[1])
+    K = torch.empty((N, N), dtype=torch.float32, device=feat.device)
+    nbytes = ((N * D * 4 + 255) // 256 + (N * 4 + 255) // 256) * 256
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=feat.device)
+    _lib.check(_lib.lib().aq_pkt_kernel_matrix(_lib.ptr(feat, name="feat"), N, D, float(eps), _lib.ptr(K), ws.data_ptr(), nbytes, _lib.stream()))
+    return K

@@ -108,3 +108,20 @@ def test_ternary_and_inq_oracle_known_answers():
     assert m.sum() == 0 and list(c) == [15, 13, 15, 14, 1, 0, 0, 16, 15]
     q2, m2, c2 = O.inq_partition(v, np.ones(9, np.uint8), 0.37, n1, n2)   # only magnitudes >= 0.37 join
     assert list(m2) == [0, 0, 0, 1, 1, 1, 1, 0, 0] and q2[3] == np.float32(-0.2) and c2[3] == 255
+
+
+def test_pkt_oracle_properties():
+    """oracle.pkt_loss (parity unpinned, restated from Passalis & Tefas 2018): zero for features with the same cosine
+    geometry, positive otherwise, invariant to a rescaling of rows."""
+    from oracle import oracle as O
+    rs = np.random.RandomState(0)
+    t = rs.standard_normal((40, 8))
+    assert abs(O.pkt_loss(t * 3.0, t)) < 1e-12
+    s = rs.standard_normal((40, 5))
+    a = O.pkt_loss(s, t)
+    assert a > 0 and abs(O.pkt_loss(s * rs.uniform(0.5, 2.0, (40, 1)), t) - a) < 1e-9
+    # two points: K = [[1, k], [k, 1]] with k = (cos + 1) / 2; orthogonal student, identical teacher rows
+    s2, t2 = np.array([[1.0, 0.0], [0.0, 1.0]]), np.array([[1.0, 0.0], [2.0, 0.0]])
+    ps = np.array([[1, .5], [.5, 1]]) / 1.5
+    pt = np.full((2, 2), 0.5)
+    assert abs(O.pkt_loss(s2, t2) - np.mean(pt * np.log((pt + 1e-7) / (ps + 1e-7)))) < 1e-9
