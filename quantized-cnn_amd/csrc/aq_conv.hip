@@ -25,6 +25,9 @@
 #include "../../include/aq_hip.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace aq {
 
@@ -326,9 +329,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a)
 // number of channels.  Same tile geometry and fragment scheme as conv_gemm_kernel, but the input channels pass
 // through LDS in chunks of CK (a multiple of 16 unless the tensor has fewer), the accumulators staying in
 // registers across chunks; k inside a chunk is (channel, tap) like everywhere else, so a chunk's k range is a
-// contiguous run of the weight matrix' k axis.  MT up to 8 (128 output channels per workgroup): with hundreds of
-// channels the 16x16x4 tiles are finally fed from one staged image for many MFMAs.
-template <int MT, int NT, int MODE>
+// contiguous run of the weight matrix' k axis.
+// WM = 1: the four wavefronts split the pixels of the tile (16*MT channels x 64*NT pixels per workgroup); WM = 4: they
+// split the output channels (64*MT channels x 16*NT pixels), every wavefront reading all pixel tiles from LDS - the
+// weight fragments, which come straight from memory, are then loaded once per workgroup instead of four times,
+// which is what layers with hundreds of channels need.
+// Stride-2 dgrad (a.par): by output parity class, blockIdx.z = 2*cy + cx.  dx[2a+cy][2b+cx] only receives the taps
+// (ty, tx) with ty = cy + pad, tx = cx + pad (mod 2), read from the UNDILATED dy at row a + (cy + pad - ty) / 2: a quarter
+// of the matrix work of the zero-dilated formulation, no zeros staged.
+struct TapClass {  // taps of one spatial dimension that reach outputs of parity c
+    int t0, nt, dmin;  // first tap, number of taps (t0, t0+2, ..), smallest input offset (that of the last tap)
+};
+__device__ __forceinline__ TapClass tap_class(int c, int pad, int ks)
+{
+    TapClass r;
+    r.t0 = (c + pad) & 1;
+    r.nt = r.t0 < ks ? (ks - r.t0 + 1) >> 1 : 0;
+    const int tl = r.t0 + 2 * (r.nt - 1);
+    r.dmin = r.nt > 0 ? (c + pad - tl) / 2 : 0;  // (exact: the numerator is even)
+    return r;
+}
+
+template <int MT, int NT, int MODE, int WM>
 __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -344,17 +366,35 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
     const int n = bx / a.tiles_y;
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int m0 = blockIdx.y * 16 * MT;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;  // tile origin in the output grid (the class grid with a.par)
+    const int m0 = blockIdx.y * 16 * MT * WM + (WM == 4 ? wave * 16 * MT : 0);
     const int ks = a.ks, ks2 = a.ks2;
+
+    // parity classes (stride-2 dgrad): taps of this class per dimension; otherwise all taps
+    const bool par = MODE == MODE_DGRAD && a.par != 0;
+    const int cy = par ? (int)blockIdx.z >> 1 : 0, cx = par ? (int)blockIdx.z & 1 : 0;
+    const int padF = ks - 1 - a.padT;  // the convolution's own padding (a.padT is that of the flipped, full correlation)
+    TapClass cty = {0, ks, 0}, ctx = {0, ks, 0};
+    if (par) {
+        cty = tap_class(cy, padF, ks);
+        ctx = tap_class(cx, padF, ks);
+    }
+    const int ktaps = cty.nt * ctx.nt;  // taps per channel that this workgroup walks (ks2 without classes)
 
     for (int k = tid; k < a.Kc; k += 256) {
         int off = 0, aoff = 0;
-        if (k < a.CK * ks2) {
-            const int c = k / ks2, tap = k - ks2 * c;
-            const int ty_ = tap / ks, tx_ = tap - ks * ty_;
-            off = c * a.plane + ty_ * a.pitch + tx_;
-            aoff = c * a.Cin * ks2 + (ks2 - 1 - tap);  // W[c0 + c (= co), ., flipped tap]
+        if (ktaps > 0 && k < a.CK * ktaps) {
+            const int c = k / ktaps, ti = k - ktaps * c;
+            if (par) {
+                const int iy = ti / ctx.nt, ix = ti - ctx.nt * iy;
+                const int ty_ = cty.t0 + 2 * iy, tx_ = ctx.t0 + 2 * ix;
+                off = c * a.plane + ((cy + padF - ty_) / 2 - cty.dmin) * a.pitch + ((cx + padF - tx_) / 2 - ctx.dmin);
+                aoff = c * a.Cin * ks2 + ty_ * ks + tx_;  // W[c0 + c (= co), ., ty, tx]: the forward tap itself
+            } else {
+                const int ty_ = ti / ks, tx_ = ti - ks * ty_;
+                off = c * a.plane + ty_ * a.pitch + tx_;
+                aoff = c * a.Cin * ks2 + (ks2 - 1 - ti);  // W[c0 + c (= co), ., flipped tap]
+            }
         }
         ktab[k] = off;
         if (MODE == MODE_DGRAD) atab[k] = aoff;
@@ -363,13 +403,17 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
         for (int i = tid; i < a.L; i += 256) qs[i] = a.q[i];
 
     int pixbase[NT];
-    int oyx[NT];  // (oy << 16) | ox, or -1 when outside the output
+    int oyx[NT];  // (oy << 16) | ox in the output tensor, or -1 when outside
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int pr = (wave * NT + t) * 16 + jn;
+        const int pr = ((WM == 4 ? 0 : wave * NT) + t) * 16 + jn;
         const int py = pr / a.TW, px = pr - py * a.TW;
         pixbase[t] = py * a.rs * a.pitch + px * a.rs;
-        const int oy = oy0 + py, ox = ox0 + px;
+        int oy = oy0 + py, ox = ox0 + px;
+        if (par) {
+            oy = 2 * oy + cy;
+            ox = 2 * ox + cx;
+        }
         oyx[t] = (oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
     }
 
@@ -379,15 +423,16 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int r0 = oy0 * a.rs - a.padT, c0 = ox0 * a.rs - a.padT;
+    const int r0 = par ? oy0 + cty.dmin : oy0 * a.rs - a.padT, c0 = par ? ox0 + ctx.dmin : ox0 * a.rs - a.padT;
+    const int dil = par ? 1 : a.dil;
     const long long chs = (long long)a.IH * a.IW;
     const float *img = a.in + (long long)n * a.KC * chs;
     const int nkb = a.Kc >> 4;
 
-    for (int cbase = 0; cbase < a.KC; cbase += a.CK) {
+    for (int cbase = 0; cbase < a.KC && ktaps > 0; cbase += a.CK) {
         const int nvalid = min(a.CK, a.KC - cbase);
-        const int kvalid = nvalid * ks2;       // k of this chunk that carry weights
-        const int kg0 = cbase * ks2;           // first global k of the chunk
+        const int kvalid = nvalid * ktaps;     // k of this chunk that carry weights
+        const int kg0 = cbase * ks2;           // first global k of the chunk (forward: k = (channel, tap))
         if (cbase) __syncthreads();            // every wavefront is done reading the previous chunk's image
         // LDS image of the chunk: rows_in x pitch per channel from (r0, c0) in (dilated) input coordinates, zero
         // outside the tensor and for channels beyond the tensor's
@@ -395,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
             const int r = e / a.pitch, cc = e - r * a.pitch;
             int gy = r0 + r, gx = c0 + cc;
             bool ok = gy >= 0 && gx >= 0;
-            if (a.dil == 2) {
+            if (dil == 2) {
                 ok = ok && !((gy | gx) & 1);
                 gy >>= 1;
                 gx >>= 1;
@@ -1325,6 +1370,129 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     conv_wgrad_body<MG, NG, CH4, J>(a, BlockCoord{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x});
 }
 
+// Weight-gradient slabs for layers with many channels: a workgroup of four wavefronts owns 64 output channels x
+// 16*NG (ci, tap) columns (for 3x3 kernels: 16 input channels exactly), wavefront w the 16 channels 16w..16w+15 with all
+// NG column tiles in its accumulators, and walks over its share of the pixel chunks (TH x TW pixels of one image): the
+// chunk's dy tile [64][pixels] and x image [channels touched][rows_in x pitch] are staged in LDS and every staged value
+// feeds 9 (dy) or 4 (x) MFMAs, four times the reuse of the small-channel kernel.  Several workgroups share a CU, so
+// one's staging overlaps another's matrix work.  Output: one slab per blockIdx.x, reduced by wgrad_reduce like the
+// other kernel's.
+template <int NG>
+__global__ __launch_bounds__(256) void conv_wgrad_big_kernel(const WgradArgs a, const int nchunks)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int npix = a.TH * a.TW;
+    float *dys = smem;                      // [64][cpitch]
+    float *xs = smem + 64 * a.cpitch;       // [CW][plane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jn = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 64;
+    const int j0 = blockIdx.z * 16 * NG;
+    const int c_lo = j0 / a.ks2;
+    const int ceff = min(a.Cin - c_lo, a.CW);
+
+    int joff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int jcol = j0 + 16 * g + jn;
+        int off = 0;
+        if (jcol < a.K9) {
+            const int ci = jcol / a.ks2, tap = jcol - a.ks2 * ci;
+            off = (ci - c_lo) * a.plane + (tap / a.ks) * a.pitch + (tap % a.ks);
+        }
+        joff[g] = off;
+    }
+    int toff[4];  // pixel 4t + kq of a 16-pixel block
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int pp = 4 * t + kq;
+        const int py = pp >> a.tw_shift, px = pp & (a.TW - 1);
+        toff[t] = py * a.stride * a.pitch + px * a.stride;
+    }
+    floatx4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const long long chs = (long long)a.Ho * a.Wo, xchs = (long long)a.H * a.Wd;
+    const int tiles = a.tiles_x * a.tiles_y;
+    for (int q = blockIdx.x; q < nchunks; q += gridDim.x) {
+        const int n = q / tiles;
+        int tr = q - n * tiles;
+        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+        const int r0 = oy0 * a.stride - a.pad, c0 = ox0 * a.stride - a.pad;
+        if (q != (int)blockIdx.x) __syncthreads();  // the previous chunk has been consumed
+        // dy tile: [64 channels][npix], zero outside the output / beyond Cout
+        const float *dsrc = a.dy + (long long)n * a.Cout * chs;
+        for (int e0 = tid; e0 < 64 * npix; e0 += 256 * 8) {  // eight loads in flight per thread, then the LDS stores
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                const int c = e >> a.npix_shift, pr = e & (npix - 1);
+                const int py = pr >> a.tw_shift, px = pr & (a.TW - 1);
+                const int oy = oy0 + py, ox = ox0 + px, co = m0 + c;
+                v[u] = (e < 64 * npix && oy < a.Ho && ox < a.Wo && co < a.Cout) ? dsrc[(long long)co * chs + oy * a.Wo + ox] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < 64 * npix) dys[(e >> a.npix_shift) * a.cpitch + (e & (npix - 1))] = v[u];
+            }
+        }
+        // x image of the channels this workgroup's columns touch
+        const float *xsrc = a.x + ((long long)n * a.Cin + c_lo) * xchs;
+        for (int e = tid; e < a.plane; e += 256) {
+            const int r = e / a.pitch, cc = e - r * a.pitch;
+            const int gy = r0 + r, gx = c0 + cc;
+            const bool ok = gy >= 0 && gx >= 0 && gy < a.H && gx < a.Wd;
+            const float *src = xsrc + (ok ? gy * a.Wd + gx : 0);
+            for (int c = 0; c < ceff; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (ok && c + u < ceff) ? src[(long long)(c + u) * xchs] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + u < ceff) xs[(c + u) * a.plane + e] = v[u];
+            }
+        }
+        __syncthreads();
+        // k = pixels: 16-pixel blocks, four MFMA steps each; two operand sets alternate
+        const float *arow = dys + (16 * wave + jn) * a.cpitch + kq;
+        const int nsteps = npix >> 2;  // multiple of 4
+        float av0, av1, bv0[NG], bv1[NG];
+        auto load_step = [&](int sidx, float &av, float (&bv)[NG]) {
+            const int s2 = sidx < nsteps ? sidx : nsteps - 1;
+            const int p16 = (s2 >> 2) * 16, t = s2 & 3;
+            const int py = p16 >> a.tw_shift, px = p16 & (a.TW - 1);
+            const int bo = py * a.stride * a.pitch + px * a.stride + toff[t];
+            av = arow[p16 + 4 * t];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bv[g] = xs[bo + joff[g]];
+        };
+        load_step(0, av0, bv0);
+        for (int sidx = 0; sidx < nsteps; sidx += 2) {
+            load_step(sidx + 1, av1, bv1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[g], acc[g], 0, 0, 0);
+            load_step(sidx + 2, av0, bv0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[g], acc[g], 0, 0, 0);
+        }
+    }
+    // D[row = 4 * kq + r][col = jn] of tile g -> slab
+    float *part = a.part + (long long)blockIdx.x * a.Cout * a.K9;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int col = j0 + 16 * g + jn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * wave + 4 * kq + r;
+            if (row < a.Cout && col < a.K9) part[(long long)row * a.K9 + col] = acc[g][r];
+        }
+    }
+}
+
 // Both gradients of one convolution in ONE launch.  The input gradient (persistent GEMM, 4 wavefronts per
 // workgroup) and the weight-gradient slabs (8 wavefronts) read the same dy and do not depend on each other;
 // each of them alone leaves most of a CU idle (latency-bound at this problem size), so their workgroups run
@@ -1485,57 +1653,84 @@ template <int MODE>
 static int launch_chunked(ConvArgs &a, int N, hipStream_t st, const char *who)
 {
     const int mtiles = (a.M + 15) / 16;
-    int MT = mtiles >= 8 ? 8 : (mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1)), NT = 2;
-    a.par = 0; a.halo = a.padT;
+    // stride-2 dgrad: by output parity classes (a quarter of the work); the class grid is half the output each way
+    const bool par = MODE == MODE_DGRAD && a.dil == 2;
+    const int gh = par ? (a.OH + 1) / 2 : a.OH, gw = par ? (a.OW + 1) / 2 : a.OW;
+    const int nclass = par ? 4 : 1;
+    a.par = par ? 1 : 0;
+    a.halo = a.padT;
+    if (par) a.rs = 1;
+    // wavefronts along the output channels once there are 64 of them (weight fragments loaded once per workgroup)
+    const int WM = mtiles >= 4 ? 4 : 1;
+    int MT, NT;  // per wavefront
+    if (WM == 4) {
+        MT = mtiles >= 8 ? 2 : 1;
+        NT = 8;
+    } else {
+        MT = mtiles >= 2 ? 2 : 1;
+        NT = 2;
+    }
+    auto npix = [&](int nt) { return 16 * nt * (WM == 4 ? 1 : 4); };
     auto blocks = [&](int mt, int nt) {
         int TW, TH;
-        pick_tile(a.OW, 64 * nt, TW, TH);
-        return (long long)N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW) * ((mtiles + mt - 1) / mt);
+        pick_tile(gw, npix(nt), TW, TH);
+        return (long long)N * ((gh + TH - 1) / TH) * ((gw + TW - 1) / TW) * nclass * ((mtiles + mt * WM - 1) / (mt * WM));
     };
-    while (blocks(MT, NT) < 512 && (NT > 1 || MT > 1)) {
-        if (MT > 4) MT >>= 1;
-        else if (NT > 1) NT = 1;
-        else MT >>= 1;
+    while (blocks(MT, NT) < 512) {  // fill the chip: smaller pixel tiles first, then fewer channels per workgroup
+        if (WM == 4 && NT > 4) NT = 4;
+        else if (WM == 1 && NT > 1) NT = 1;
+        else if (MT > 1) MT = 1;
+        else break;
     }
-    if (NT > 1) {
+    {
         int tw, th;
-        pick_tile(a.OW, 128, tw, th);
-        if (th > a.OH) NT = 1;
+        pick_tile(gw, npix(NT), tw, th);
+        if (th > gh && ((WM == 4 && NT > 4) || (WM == 1 && NT > 1))) NT >>= 1;  // a tile taller than the grid would be half empty
     }
-    pick_tile(a.OW, 64 * NT, a.TW, a.TH);
-    a.tiles_x = (a.OW + a.TW - 1) / a.TW;
-    a.tiles_y = (a.OH + a.TH - 1) / a.TH;
-    a.pitch = (a.TW - 1) * a.rs + a.ks;
-    a.rows_in = (a.TH - 1) * a.rs + a.ks;
+    pick_tile(gw, npix(NT), a.TW, a.TH);
+    a.tiles_x = (gw + a.TW - 1) / a.TW;
+    a.tiles_y = (gh + a.TH - 1) / a.TH;
+    if (par) {  // undilated dy tile: one input pixel per output pixel of the class plus the taps' reach
+        const int reach = (a.ks - 1) / 2 + 1;  // at most ceil(ks / 2) taps per dimension -> that many distinct offsets
+        a.pitch = a.TW + reach;
+        a.rows_in = a.TH + reach;
+    } else {
+        a.pitch = (a.TW - 1) * a.rs + a.ks;
+        a.rows_in = (a.TH - 1) * a.rs + a.ks;
+    }
     a.plane = a.rows_in * a.pitch;
+    const int taps = par ? ((a.ks + 1) / 2) * ((a.ks + 1) / 2) : a.ks2;  // most taps any class walks per channel
     // channels per chunk: about 144 k per chunk (nine k-blocks between two barriers), within 48 KiB of LDS
     int CK = a.KC;
     if (a.KC >= 16) {
-        const int want = std::max(16, ((144 / a.ks2) + 15) & ~15);
+        const int want = std::max(16, ((144 / taps) + 15) & ~15);
         const int fit = (int)((48 * 1024) / ((size_t)a.plane * 4)) & ~15;
         CK = std::max(16, std::min(want, fit));
         CK = std::min(CK, (a.KC + 15) & ~15);
     }
     a.CK = CK;
-    a.Kc = (CK * a.ks2 + 15) & ~15;
+    a.Kc = (CK * taps + 15) & ~15;
     a.Kpad = a.Kc;
     a.vecA = (a.K % 4 == 0) && (((uintptr_t)a.W & 15) == 0) && ((CK * a.ks2) % 4 == 0);
     const size_t lds = (size_t)a.Kc * 4 * (MODE == MODE_DGRAD ? 2 : 1) + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) * 4 : 0) + (size_t)CK * a.plane * 4;
     AQ_REQUIRE(lds <= 64 * 1024, -E2BIG, "%s: input tile needs %zu bytes of LDS (limit 65536)", who, lds);
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     AQ_REQUIRE(gx < (1LL << 31), -E2BIG, "%s: grid too large", who);
-    const unsigned gy = (unsigned)((mtiles + MT - 1) / MT);
+    const unsigned gy = (unsigned)((mtiles + MT * WM - 1) / (MT * WM));
     AQ_REQUIRE(gy < 65536, -E2BIG, "%s: too many output channels", who);
-    dim3 grid((unsigned)gx, gy);
-#define AQ_CH(MM, NN) hipLaunchKernelGGL((conv_gemm_chunked_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
-    if (MT == 8 && NT == 2) AQ_CH(8, 2);
-    else if (MT == 8) AQ_CH(8, 1);
-    else if (MT == 4 && NT == 2) AQ_CH(4, 2);
-    else if (MT == 4) AQ_CH(4, 1);
-    else if (MT == 2 && NT == 2) AQ_CH(2, 2);
-    else if (MT == 2) AQ_CH(2, 1);
-    else if (NT == 2) AQ_CH(1, 2);
-    else AQ_CH(1, 1);
+    dim3 grid((unsigned)gx, gy, (unsigned)nclass);
+#define AQ_CH(MM, NN, WW) hipLaunchKernelGGL((conv_gemm_chunked_kernel<MM, NN, MODE, WW>), grid, dim3(256), lds, st, a)
+    if (WM == 4) {
+        if (MT == 2 && NT == 8) AQ_CH(2, 8, 4);
+        else if (MT == 2) AQ_CH(2, 4, 4);
+        else if (NT == 8) AQ_CH(1, 8, 4);
+        else AQ_CH(1, 4, 4);
+    } else {
+        if (MT == 2 && NT == 2) AQ_CH(2, 2, 1);
+        else if (MT == 2) AQ_CH(2, 1, 1);
+        else if (NT == 2) AQ_CH(1, 2, 1);
+        else AQ_CH(1, 1, 1);
+    }
 #undef AQ_CH
     return check_launch(who);
 }
@@ -1868,6 +2063,19 @@ static int wgrad_bank_cost(int pitch, int plane, int stride, int K9)
 // pitch (<= 65) and plane of the LDS x image, padded so that the operand reads spread over the banks
 static void wgrad_pad(int stride, int K9, int rows_in, int &pitch, int &plane)
 {
+    // the search costs about a millisecond of host time: remembered per geometry (plans are made on every call)
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> memo;
+    const auto key = std::make_tuple(stride, K9, rows_in, pitch);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto it = memo.find(key);
+        if (it != memo.end()) {
+            pitch = it->second.first;
+            plane = it->second.second;
+            return;
+        }
+    }
     int best = 1 << 30, bp = pitch, bpl = rows_in * pitch;
     const int limit = ((rows_in * pitch + 63) / 64) * 64;  // same number of 64-element slices as unpadded
     for (int p = pitch; p <= pitch + 8 && p <= 65; ++p)
@@ -1879,6 +2087,8 @@ static void wgrad_pad(int stride, int K9, int rows_in, int &pitch, int &plane)
         }
     pitch = bp;
     plane = bpl;
+    std::lock_guard<std::mutex> lock(mu);
+    memo[key] = std::make_pair(bp, bpl);
 }
 
 static int wgrad_plan_with(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_t &lds, size_t &ws_bytes, int ng_cap, int npix_cap);
@@ -1960,11 +2170,75 @@ static int wgrad_plan_with(aq::WgradArgs &a, int &MG, int &NG, dim3 &grid, size_
     return 0;
 }
 
+static int wgrad_variant(const aq::WgradArgs &a, int MG, int NG);
+
+// Plan of conv_wgrad_big_kernel, used for layers with at least 64 output channels and 144 (ci, tap) columns that
+// have no tuned variant of the small-channel kernel (the reference's ResNet-20 shapes keep theirs).
+struct WgradBigPlan {
+    bool use;
+    int nchunks, nslab;
+    dim3 grid;
+    size_t lds, ws_bytes;
+};
+static WgradBigPlan wgrad_big_plan(aq::WgradArgs &a)
+{
+    using namespace aq;
+    WgradBigPlan p = {};
+    if (a.ks == 0) { a.ks = 3; a.pad = 1; }
+    a.ks2 = a.ks * a.ks;
+    a.Ho = conv_out(a.H, a.ks, a.stride, a.pad);
+    a.Wo = conv_out(a.Wd, a.ks, a.stride, a.pad);
+    a.K9 = a.Cin * a.ks2;
+    if (a.Cout < 64 || a.K9 < 144) return p;
+    {
+        WgradArgs t = a;
+        int MGs, NGs;
+        dim3 g;
+        size_t l, w;
+        if (wgrad_plan(t, MGs, NGs, g, l, w) == 0 && wgrad_variant(t, MGs, NGs) != 0) return p;
+    }
+    constexpr int NG = 9;
+    pick_tile(a.Wo, (long long)a.Ho * a.Wo <= 64 ? 64 : 128, a.TW, a.TH);
+    a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
+    a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
+    a.pitch = (a.TW - 1) * a.stride + a.ks;
+    a.rows_in = (a.TH - 1) * a.stride + a.ks;
+    a.plane = a.rows_in * a.pitch;
+    a.cpitch = a.TH * a.TW + 4;  // row pitch = 4 mod 64 banks: the 16 rows x 4 pixels of an operand read hit 64 banks
+    a.tw_shift = a.npix_shift = 0;
+    while ((1 << a.tw_shift) < a.TW) ++a.tw_shift;
+    while ((1 << a.npix_shift) < a.TH * a.TW) ++a.npix_shift;
+    const int ncol_tiles = (a.K9 + 15) / 16, gz = (ncol_tiles + NG - 1) / NG;
+    a.CW = 1;
+    for (int z = 0; z < gz; ++z) {
+        const int j0 = z * 16 * NG, j1 = std::min(a.K9, j0 + 16 * NG) - 1;
+        a.CW = std::max(a.CW, j1 / a.ks2 - j0 / a.ks2 + 1);
+    }
+    p.lds = ((size_t)64 * a.cpitch + (size_t)a.CW * a.plane) * 4;
+    if (p.lds > 64 * 1024) return p;
+    const int gy = (a.Cout + 63) / 64;
+    p.nchunks = a.N * a.tiles_x * a.tiles_y;
+    // slabs: enough workgroups to fill the chip a few times over, at least ~4 chunks each, at most 256 slabs
+    long long want = (1024 + (long long)gy * gz - 1) / ((long long)gy * gz);
+    want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (p.nchunks + 3) / 4));
+    p.nslab = (int)std::min<long long>(want, p.nchunks);
+    if (gy >= 65536 || gz >= 65536) return p;
+    p.grid = dim3((unsigned)p.nslab, (unsigned)gy, (unsigned)gz);
+    p.ws_bytes = (size_t)p.nslab * a.Cout * a.K9 * 4;
+    p.use = true;
+    return p;
+}
+
 size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
 {
     if (aq::check_conv("aq_conv_wgrad_workspace_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     aq::WgradArgs a = {};
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ksize; a.pad = pad;
+    {
+        aq::WgradArgs b = a;
+        const WgradBigPlan bp = wgrad_big_plan(b);
+        if (bp.use) return bp.ws_bytes;
+    }
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
@@ -2112,6 +2386,17 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     a.x = x; a.dy = dy; a.part = static_cast<float *>(workspace);
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
+    if (!bn) {
+        WgradArgs b = a;
+        const WgradBigPlan bp = wgrad_big_plan(b);
+        if (bp.use) {
+            AQ_REQUIRE(workspace && workspace_bytes >= bp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", bp.ws_bytes,
+                       workspace_bytes);
+            hipLaunchKernelGGL(conv_wgrad_big_kernel<9>, bp.grid, dim3(256), bp.lds, st, b, bp.nchunks);
+            *nslab_out = bp.nslab;
+            return check_launch("aq_conv_wgrad");
+        }
+    }
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
