@@ -147,6 +147,46 @@ def kernel_rooflines(quick):
             more.append({"bound": "mfma", "kernel": "%s %d->%d s%d %dx%d N=%d" % (name, cin, cout, s, H, H, BATCH),
                          "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+    # ---- kernels of the quantiser modes and shapes that have no reference code (parity unpinned) ----
+    torch.cuda.empty_cache()
+    n = 250_000_000 if not quick else 25_000_000
+    w = torch.randn(n, device=dev) * 0.05
+    gw = torch.randn(n, device=dev)
+    tq = event_time(lambda: ops.tern_forward([w], "twn", decoded=False), 10)
+    more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel + tern_emit_kernel<false> + second stages (threshold 0.7*mean|w|, 1-byte codes)",
+                 "achieved": round(n * 9 / tq / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 9 / tq / 1e9 / HBM_PEAK_GBS, 4),
+                 "bytes_per_weight": 9, "weights_per_call": n, "avg_call_ms": round(tq * 1e3, 4), "parity": "unpinned (no reference implementation)"})
+    Wp, Wn = [torch.full((1,), 0.1, device=dev)], [torch.full((1,), 0.08, device=dev)]
+    st = ops.tern_forward([w], "ttq", Wp=Wp, Wn=Wn)[0]["stats"]
+    tb = event_time(lambda: ops.tern_backward([w], [gw], "ttq", stats=[st], Wp=Wp, Wn=Wn), 10)
+    more.append({"bound": "hbm", "kernel": "aq::tern_bwd_kernel<1> (TTQ straight-through + scale gradients)", "achieved": round(n * 12 / tb / 1e9, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 12 / tb / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_weight": 12, "weights_per_call": n,
+                 "avg_call_ms": round(tb * 1e3, 4), "parity": "unpinned (no reference implementation)"})
+    del w, gw
+    torch.cuda.empty_cache()
+    B18 = 32
+    for (cin, cout, ks, s, pd, H) in [(3, 64, 7, 2, 3, 224), (64, 64, 3, 1, 1, 56), (128, 128, 3, 1, 1, 28), (256, 256, 3, 1, 1, 14), (512, 512, 3, 1, 1, 7),
+                                      (128, 256, 3, 2, 1, 28)]:
+        x = torch.randn(B18, cin, H, H, device=dev)
+        Wc = torch.randn(cout, cin, ks, ks, device=dev) * 0.05
+        y = ops.conv_forward(x, Wc, s, pad=pd)
+        dy = torch.randn_like(y)
+        fl = 2.0 * B18 * cout * cin * ks * ks * y.shape[2] * y.shape[3]
+        for name, fn in (("conv_fwd", lambda: ops.conv_forward(x, Wc, s, pad=pd)), ("conv_dgrad", lambda: ops.conv_dgrad(dy, Wc, x.shape, s, pad=pd)),
+                         ("conv_wgrad", lambda: ops.conv_wgrad(x, dy, s, ks=ks, pad=pd))):
+            if name == "conv_dgrad" and cin == 3:
+                continue  # the stem's input needs no gradient
+            t = event_time(fn, 5, 2)
+            more.append({"bound": "mfma", "kernel": "%s %d->%d k%d s%d %dx%d N=%d (ResNet-18 shape, general kernels; no reference model)" % (
+                name, cin, cout, ks, s, H, H, B18), "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+    for D in (64, 512):
+        f = torch.randn(1024, D, device=dev)
+        t = event_time(lambda: ops.pkt_kernel_matrix(f), 10)
+        fl = 2.0 * 1024 * 1024 * D
+        more.append({"bound": "mfma", "kernel": "PKT cosine-kernel matrix, batch 1024 x %d features (normalise + aq::pkt_gemm_nt_kernel<true>)" % D,
+                     "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4),
+                     "avg_call_us": round(t * 1e6, 2), "parity": "unpinned (no reference implementation)"})
     return roof, more
 
 

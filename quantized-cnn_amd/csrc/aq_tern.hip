@@ -37,12 +37,15 @@ struct TernSegDev {
     float *q;              // [3] codebook
     const float *wp, *wn;
     float *dwp, *dwn;
-    float *part;           // per-wavefront partials of this layer
+    float *part;           // per-workgroup partials of this layer
+    float *part2;          // second level: one partial per LEVEL_CHUNK first-level partials (layers with many of them)
     long long n;
     int blk0, nwave;
+    int n2;                // number of second-level partials (0: the last stage reads the first level)
 };
 struct TernTab {
     int nseg;
+    int nt;  // tensors beyond the last-level cache: streaming (nontemporal) loads and stores
     TernSegDev s[TERN_MAX_SEGS];
 };
 
@@ -67,19 +70,43 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// element range [e0, e1) of wavefront `wt` of a layer, and this lane's share: elements e0 + 256*u + 4*lane + k
-__device__ __forceinline__ void load8(const float *__restrict__ w, long long e0, long long n, int lane, float (&v)[8][4], bool vec)
+// One partial per wavefront and quantity, written by lane 0: no barrier, so a wavefront retires as soon as its own
+// loads are consumed (with a workgroup-level sum the streaming kernels measured 3-4 % slower).  Layers with
+// thousands of partials get a middle reduction stage (tern_level_kernel).
+template <int F>
+__device__ __forceinline__ void wave_partials(const float (&vals)[F], float *part, int wt, int nwave)
 {
+    if ((threadIdx.x & 63) == 0 && wt < nwave) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) part[wt * F + f] = vals[f];
+    }
+}
+
+// element range [e0, e1) of wavefront `wt` of a layer, and this lane's share: elements e0 + 256*u + 4*lane + k
+typedef float tern_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load8(const float *__restrict__ w, long long e0, long long n, int lane, float (&v)[8][4], bool vec, bool nt = false)
+{
+    if (vec && e0 + TERN_ELEMS_PER_WAVE <= n) {  // whole wavefront inside the tensor (uniform): eight loads issued back to back
+        const tern_f4 *src = reinterpret_cast<const tern_f4 *>(w + e0) + lane;
+        tern_f4 t[8];
+        if (nt) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(src + 64 * u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u][0] = t[u].x; v[u][1] = t[u].y; v[u][2] = t[u].z; v[u][3] = t[u].w;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const long long e = e0 + 256 * u + 4 * lane;
-        if (vec && e + 3 < n) {
-            const float4 t = *reinterpret_cast<const float4 *>(w + e);
-            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
-        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[u][k] = e + k < n ? w[e + k] : 0.0f;
-        }
+        for (int k = 0; k < 4; ++k) v[u][k] = e + k < n ? w[e + k] : 0.0f;
     }
 }
 
@@ -89,11 +116,11 @@ __global__ __launch_bounds__(256) void tern_absstat_kernel(const TernTab tab)
     const int si = tern_segment(tab);
     const TernSegDev &s = tab.s[si];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
-    if (wt >= s.nwave) return;
-    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    const int blk = (int)blockIdx.x - s.blk0;
+    const int wt = blk * 4 + wave;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;  // (wavefronts beyond the layer load nothing: all zeros)
     float v[8][4];
-    load8(s.w, e0, s.n, lane, v, ((uintptr_t)s.w & 15) == 0);
+    load8(s.w, e0, s.n, lane, v, ((uintptr_t)s.w & 15) == 0, tab.nt != 0);
     float sum = 0.0f, mx = 0.0f;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -103,22 +130,27 @@ __global__ __launch_bounds__(256) void tern_absstat_kernel(const TernTab tab)
             sum += a;
             mx = fmaxf(mx, a);
         }
-    sum = wave_sum(sum);
-    mx = wave_max(mx);
-    if (lane == 0) {
-        s.part[2 * wt] = sum;
-        s.part[2 * wt + 1] = mx;
-    }
+    const float vals[2] = {wave_sum(sum), wave_max(mx)};
+    wave_partials<2>(vals, s.part, wt, s.nwave);
 }
 
 // fixed-order sum of `cnt` strided values: thread t adds t, t+256, ..; then a halving tree over the threads
 __device__ __forceinline__ float block_sum_strided(const float *p, int cnt, int stride, float *sh)
 {
     float a = 0.0f;
-    for (int i = threadIdx.x; i < cnt; i += 256) a += p[(long long)i * stride];
+    const int T = blockDim.x;  // 256 or 1024 threads (a power of two)
+    int i = threadIdx.x;
+    for (; i + T * 7 < cnt; i += T * 8) {  // eight independent loads in flight, added in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(i + T * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; i < cnt; i += T) a += p[(long long)i * stride];
     sh[threadIdx.x] = a;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = T >> 1; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
@@ -129,10 +161,11 @@ __device__ __forceinline__ float block_sum_strided(const float *p, int cnt, int 
 __device__ __forceinline__ float block_max_strided(const float *p, int cnt, int stride, float *sh)
 {
     float a = 0.0f;
-    for (int i = threadIdx.x; i < cnt; i += 256) a = fmaxf(a, p[(long long)i * stride]);
+    const int T = blockDim.x;
+    for (int i = threadIdx.x; i < cnt; i += T) a = fmaxf(a, p[(long long)i * stride]);
     sh[threadIdx.x] = a;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = T >> 1; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
@@ -141,13 +174,35 @@ __device__ __forceinline__ float block_max_strided(const float *p, int cnt, int 
     return r;
 }
 
-// B: delta of every layer (one workgroup per layer)
-__global__ __launch_bounds__(256) void tern_delta_kernel(const TernTab tab, const float factor, const int thr_max)
+// Middle stage for layers with thousands of first-level partials: workgroup b adds (or maximises) the partials
+// [b * LEVEL_CHUNK, (b + 1) * LEVEL_CHUNK) of every quantity, in a fixed order, into one second-level partial.
+constexpr int LEVEL_CHUNK = 8192;
+template <int F, int MAXF>
+__global__ __launch_bounds__(1024) void tern_level_kernel(const float *__restrict__ src, int cnt, float *__restrict__ dst)
 {
-    __shared__ float sh[256];
+    __shared__ float sh[1024];
+    const int lo = blockIdx.x * LEVEL_CHUNK, c = min(LEVEL_CHUNK, cnt - lo);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const float r = (f == MAXF) ? block_max_strided(src + (long long)lo * F + f, c, F, sh) : block_sum_strided(src + (long long)lo * F + f, c, F, sh);
+        if (threadIdx.x == 0) dst[blockIdx.x * F + f] = r;
+    }
+}
+__device__ __forceinline__ const float *last_level(const TernSegDev &s, int &cnt)
+{
+    cnt = s.n2 ? s.n2 : s.nwave;
+    return s.n2 ? s.part2 : s.part;
+}
+
+// B: delta of every layer (one workgroup per layer)
+__global__ __launch_bounds__(1024) void tern_delta_kernel(const TernTab tab, const float factor, const int thr_max)
+{
+    __shared__ float sh[1024];
     const TernSegDev &s = tab.s[blockIdx.x];
-    const float sum = block_sum_strided(s.part, s.nwave, 2, sh);
-    const float mx = block_max_strided(s.part + 1, s.nwave, 2, sh);
+    int nblk;
+    const float *pp = last_level(s, nblk);
+    const float sum = block_sum_strided(pp, nblk, 2, sh);
+    const float mx = block_max_strided(pp + 1, nblk, 2, sh);
     if (threadIdx.x == 0) {
         const float mean = sum / (float)s.n;
         s.stats[0] = factor * (thr_max ? mx : mean);
@@ -161,8 +216,8 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
     const int si = tern_segment(tab);
     const TernSegDev &s = tab.s[si];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
-    if (wt >= s.nwave) return;
+    const int blk = (int)blockIdx.x - s.blk0;
+    const int wt = blk * 4 + wave;
     const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
     const float delta = s.stats[0];
     float pos = 0.0f, neg = 0.0f;
@@ -172,7 +227,7 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
     }
     float v[8][4];
     const bool vec = ((uintptr_t)s.w & 15) == 0;
-    load8(s.w, e0, s.n, lane, v, vec);
+    load8(s.w, e0, s.n, lane, v, vec, tab.nt != 0);
     float sabs = 0.0f, npos = 0.0f, nneg = 0.0f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -223,25 +278,21 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
             }
         }
     }
-    sabs = wave_sum(sabs);
-    npos = wave_sum(npos);
-    nneg = wave_sum(nneg);
-    if (lane == 0) {
-        s.part[4 * wt] = sabs;
-        s.part[4 * wt + 1] = npos;
-        s.part[4 * wt + 2] = nneg;
-    }
+    const float vals[3] = {wave_sum(sabs), wave_sum(npos), wave_sum(nneg)};
+    wave_partials<3>(vals, s.part, wt, s.nwave);
 }
 
 // D: codebook of every layer.  TWN: alpha = mean of |w| above delta for both signs; TTQ: the learned scales.
 template <bool TTQ>
-__global__ __launch_bounds__(256) void tern_codebook_kernel(const TernTab tab)
+__global__ __launch_bounds__(1024) void tern_codebook_kernel(const TernTab tab)
 {
-    __shared__ float sh[256];
+    __shared__ float sh[1024];
     const TernSegDev &s = tab.s[blockIdx.x];
-    const float sabs = block_sum_strided(s.part, s.nwave, 4, sh);
-    const float npos = block_sum_strided(s.part + 1, s.nwave, 4, sh);
-    const float nneg = block_sum_strided(s.part + 2, s.nwave, 4, sh);
+    int nblk;
+    const float *pp = last_level(s, nblk);
+    const float sabs = block_sum_strided(pp, nblk, 3, sh);
+    const float npos = block_sum_strided(pp + 1, nblk, 3, sh);
+    const float nneg = block_sum_strided(pp + 2, nblk, 3, sh);
     if (threadIdx.x == 0) {
         const float cnt = npos + nneg;
         float pos, neg;
@@ -291,8 +342,8 @@ __global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
     const int si = tern_segment(tab);
     const TernSegDev &s = tab.s[si];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
-    if (wt >= s.nwave) return;
+    const int blk = (int)blockIdx.x - s.blk0;
+    const int wt = blk * 4 + wave;
     const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
     float delta = 0.0f, pos = 1.0f, neg = 1.0f;
     if (MODE == 1) {
@@ -302,8 +353,8 @@ __global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
     }
     float g[8][4], v[8][4];
     const bool vec = (((uintptr_t)s.dwt | (uintptr_t)s.dw | (uintptr_t)s.w) & 15) == 0;
-    load8(s.dwt, e0, s.n, lane, g, vec);
-    if (MODE == 1) load8(s.w, e0, s.n, lane, v, vec);
+    load8(s.dwt, e0, s.n, lane, g, vec, tab.nt != 0);
+    if (MODE == 1) load8(s.w, e0, s.n, lane, v, vec, tab.nt != 0);
     float sp = 0.0f, sn = 0.0f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -326,30 +377,31 @@ __global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
             }
             o[k] = d;
         }
-        if (vec && e + 3 < s.n) *reinterpret_cast<float4 *>(s.dw + e) = make_float4(o[0], o[1], o[2], o[3]);
-        else {
+        if (vec && e + 3 < s.n) {
+            const tern_f4 t = {o[0], o[1], o[2], o[3]};
+            if (tab.nt) __builtin_nontemporal_store(t, reinterpret_cast<tern_f4 *>(s.dw + e));
+            else *reinterpret_cast<tern_f4 *>(s.dw + e) = t;
+        } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (e + k < s.n) s.dw[e + k] = o[k];
         }
     }
     if (MODE == 1) {
-        sp = wave_sum(sp);
-        sn = wave_sum(sn);
-        if (lane == 0) {
-            s.part[2 * wt] = sp;
-            s.part[2 * wt + 1] = sn;
-        }
+        const float vals[2] = {wave_sum(sp), wave_sum(sn)};
+        wave_partials<2>(vals, s.part, wt, s.nwave);
     }
 }
 
 // d loss / d Wp = sum over the positives of dwt;  d loss / d Wn = - sum over the negatives (w~ = -Wn there)
-__global__ __launch_bounds__(256) void tern_scale_grad_kernel(const TernTab tab)
+__global__ __launch_bounds__(1024) void tern_scale_grad_kernel(const TernTab tab)
 {
-    __shared__ float sh[256];
+    __shared__ float sh[1024];
     const TernSegDev &s = tab.s[blockIdx.x];
-    const float sp = block_sum_strided(s.part, s.nwave, 2, sh);
-    const float sn = block_sum_strided(s.part + 1, s.nwave, 2, sh);
+    int nblk;
+    const float *pp = last_level(s, nblk);
+    const float sp = block_sum_strided(pp, nblk, 2, sh);
+    const float sn = block_sum_strided(pp + 1, nblk, 2, sh);
     if (threadIdx.x == 0) {
         if (s.dwp) s.dwp[0] = sp;
         if (s.dwn) s.dwn[0] = -sn;
@@ -399,10 +451,19 @@ __global__ __launch_bounds__(256) void inq_partition_kernel(float *__restrict__ 
 
 static inline int tern_waves(long long n) { return (int)((n + TERN_ELEMS_PER_WAVE - 1) / TERN_ELEMS_PER_WAVE); }
 
+static inline int tern_level2(long long n)
+{
+    const int nw = tern_waves(n);
+    return nw > 2048 ? (nw + LEVEL_CHUNK - 1) / LEVEL_CHUNK : 0;
+}
+static inline size_t tern_seg_bytes(long long n)
+{
+    return ((((size_t)tern_waves(n) * 4 * sizeof(float)) + 255) & ~(size_t)255) + ((((size_t)tern_level2(n) * 4 * sizeof(float)) + 255) & ~(size_t)255);
+}
 static size_t tern_ws_bytes(const aq_tern_seg *segs, int nseg)
 {
     size_t off = 0;
-    for (int i = 0; i < nseg; ++i) off += (((size_t)tern_waves(segs[i].n) * 4 * sizeof(float)) + 255) & ~(size_t)255;
+    for (int i = 0; i < nseg; ++i) off += tern_seg_bytes(segs[i].n);
     return off;
 }
 
@@ -419,6 +480,9 @@ static int tern_validate(const char *who, const aq_tern_seg *segs, int nseg)
 static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTab &tab)
 {
     tab.nseg = nseg;
+    long long total = 0;
+    for (int i = 0; i < nseg; ++i) total += segs[i].n;
+    tab.nt = total * 4 > (128LL << 20) ? 1 : 0;
     size_t off = 0;
     long long blocks = 0;
     for (int i = 0; i < nseg; ++i) {
@@ -429,12 +493,30 @@ static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTa
         d.n = s.n;
         d.nwave = tern_waves(s.n);
         d.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + off);
-        off += (((size_t)d.nwave * 4 * sizeof(float)) + 255) & ~(size_t)255;
+        d.n2 = tern_level2(s.n);
+        d.part2 = reinterpret_cast<float *>(static_cast<char *>(workspace) + off + ((((size_t)d.nwave * 4 * sizeof(float)) + 255) & ~(size_t)255));
+        off += tern_seg_bytes(s.n);
         d.blk0 = (int)blocks;
         blocks += (d.nwave + 3) / 4;
         if (blocks >= (1LL << 31)) return -1;
     }
     return (int)blocks;
+}
+
+template <int F, int MAXF>
+static void launch_levels(const TernTab &tab, hipStream_t st)
+{
+    for (int i = 0; i < tab.nseg; ++i)
+        if (tab.s[i].n2)
+            hipLaunchKernelGGL((tern_level_kernel<F, MAXF>), dim3(tab.s[i].n2), dim3(1024), 0, st, tab.s[i].part, tab.s[i].nwave, tab.s[i].part2);
+}
+
+// threads of the one-workgroup-per-layer second stages: 1024 once some layer has thousands of partials
+static int second_stage_threads(const TernTab &tab)
+{
+    int most = 0;
+    for (int i = 0; i < tab.nseg; ++i) most = std::max(most, tab.s[i].n2 ? tab.s[i].n2 : tab.s[i].nwave);
+    return most > 2048 ? 1024 : 256;
 }
 
 } // namespace aq
@@ -469,13 +551,16 @@ int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int t
     AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_fwd: too many elements for one launch");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(tern_absstat_kernel, dim3(blocks), dim3(256), 0, st, tab);
-    hipLaunchKernelGGL(tern_delta_kernel, dim3(nseg), dim3(256), 0, st, tab, factor, threshold_from_max ? 1 : 0);
+    launch_levels<2, 1>(tab, st);
+    hipLaunchKernelGGL(tern_delta_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab, factor, threshold_from_max ? 1 : 0);
     if (mode == AQ_TERN_TTQ) {
         hipLaunchKernelGGL(tern_emit_kernel<true>, dim3(blocks), dim3(256), 0, st, tab);
-        hipLaunchKernelGGL(tern_codebook_kernel<true>, dim3(nseg), dim3(256), 0, st, tab);
+        launch_levels<3, -1>(tab, st);
+        hipLaunchKernelGGL(tern_codebook_kernel<true>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else {
         hipLaunchKernelGGL(tern_emit_kernel<false>, dim3(blocks), dim3(256), 0, st, tab);
-        hipLaunchKernelGGL(tern_codebook_kernel<false>, dim3(nseg), dim3(256), 0, st, tab);
+        launch_levels<3, -1>(tab, st);
+        hipLaunchKernelGGL(tern_codebook_kernel<false>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
         if (decode) hipLaunchKernelGGL(tern_decode_kernel, dim3(blocks), dim3(256), 0, st, tab);
     }
     return check_launch("aq_tern_fwd");
@@ -500,7 +585,8 @@ int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, si
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == AQ_TERN_TTQ) {
         hipLaunchKernelGGL(tern_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, tab);
-        hipLaunchKernelGGL(tern_scale_grad_kernel, dim3(nseg), dim3(256), 0, st, tab);
+        launch_levels<2, -1>(tab, st);
+        hipLaunchKernelGGL(tern_scale_grad_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else if (mode == AQ_TERN_INQ) {
         hipLaunchKernelGGL(tern_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, tab);
     } else {

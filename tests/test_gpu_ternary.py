@@ -26,7 +26,7 @@ def cu(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
 
 
-@pytest.mark.parametrize("n", [1, 3, 5, 16, 17, 255, 2048, 2049, 36864, 1_000_003])
+@pytest.mark.parametrize("n", [1, 3, 5, 16, 17, 255, 2048, 2049, 36864, 1_000_003, 40_000_001])  # the last: second-level partials, streaming loads
 @pytest.mark.parametrize("mode,from_max,factor", [("twn", False, 0.7), ("ttq", True, 0.05), ("ttq", False, 0.7)])
 def test_ternary_forward_vs_oracle(n, mode, from_max, factor):
     rs = np.random.RandomState(n % 9973 + int(factor * 100))
@@ -77,7 +77,7 @@ def test_ternary_forward_many_layers_one_call_and_determinism():
         ops.tern_forward(ws[:1], "ttq")
 
 
-@pytest.mark.parametrize("n", [1, 7, 2048, 70001])
+@pytest.mark.parametrize("n", [1, 7, 2048, 70001, 40_000_001])
 def test_ternary_backward_vs_oracle(n):
     rs = np.random.RandomState(n)
     w = (rs.standard_normal(n) * 0.05).astype(np.float32)
