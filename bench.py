@@ -69,21 +69,22 @@ def kernel_rooflines(quick):
     t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20)
     t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 10)
     # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc on the same
-    # 250 M-element tensor, see profiles/roofline_traffic.json); only valid for the full-size tensor
-    traffic = traffic2 = traffic3 = None
-    tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    # 250 M-element tensor, see profiles/r02_roofline_traffic.json); only valid for the full-size tensor
+    traffic = traffic2 = traffic3 = traffic_codes = traffic_tern = None
+    tf = os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")
     if os.path.exists(tf) and not quick:
         try:
             tj = json.load(open(tf))
             if tj.get("rows_per_launch") == rows:
                 traffic, traffic2 = tj.get("synth_fwd_bytes_per_launch"), tj.get("synth_bwd_bytes_per_launch")
                 traffic3 = tj.get("synth_bwd_adam_bytes_per_launch")
+                traffic_codes, traffic_tern = tj.get("synth_fwd_codes_only_bytes_per_launch"), tj.get("tern_quantise_bytes_per_call")
         except Exception:
-            traffic = traffic2 = traffic3 = None
+            traffic = traffic2 = traffic3 = traffic_codes = traffic_tern = None
     a1 = rows * (4 * L + 4) / t1 / 1e9
     # traffic: not measured in this run; the committed PMC result for the same launch (FETCH_SIZE x 2 + WRITE_SIZE)
-    src = "profiles/roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
-    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
+    src = "profiles/r02_roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
+    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
@@ -94,12 +95,12 @@ def kernel_rooflines(quick):
     th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=False, codes=True), 10)
     ah = rows * (4 * L + 5) / th / 1e9
     more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, true> (codes + q[code]; arg-max of p, exact sequence on near ties)",
-                 "achieved": round(ah, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "bytes_per_row": 4 * L + 5,
-                 "rows_per_launch": rows, "avg_launch_ms": round(th * 1e3, 4)})
+                 "achieved": round(ah, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "traffic": traffic_codes,
+                 "bytes_per_row": 4 * L + 5, "rows_per_launch": rows, "avg_launch_ms": round(th * 1e3, 4)})
     # soft W, codes and q[code] together in exact arithmetic (bit-reproducible against the CPU restatement)
     th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, codes=True), 10)
     ah = rows * (4 * L + 9) / th / 1e9
-    more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true> (W + codes + q[code], exact arithmetic)", "achieved": round(ah, 1),
+    more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, false> (W + codes + q[code], exact arithmetic)", "achieved": round(ah, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "bytes_per_row": 4 * L + 9, "rows_per_launch": rows,
                  "avg_launch_ms": round(th * 1e3, 4)})
     # 31 levels (adp_qtz_fix): 124-byte rows, no 16-byte alignment
@@ -109,7 +110,7 @@ def kernel_rooflines(quick):
     dp31 = [dp[0].view(-1)[:rows * L31].view(rows, L31)]
     t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 10)
     t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 10)
-    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 0, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 0, false, false> (L = 31)", t31b, 8 * L31 + 4)):
+    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 0, false, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 0, false, false> (L = 31)", t31b, 8 * L31 + 4)):
         aa = rows * bpr / tt / 1e9
         more.append({"bound": "hbm", "kernel": nm, "achieved": round(aa, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(aa / HBM_PEAK_GBS, 4),
                      "bytes_per_row": bpr, "rows_per_launch": rows, "avg_launch_ms": round(tt * 1e3, 4)})
@@ -155,7 +156,7 @@ def kernel_rooflines(quick):
     tq = event_time(lambda: ops.tern_forward([w], "twn", decoded=False), 10)
     more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel + tern_emit_kernel<false> + second stages (threshold 0.7*mean|w|, 1-byte codes)",
                  "achieved": round(n * 9 / tq / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 9 / tq / 1e9 / HBM_PEAK_GBS, 4),
-                 "bytes_per_weight": 9, "weights_per_call": n, "avg_call_ms": round(tq * 1e3, 4), "parity": "unpinned (no reference implementation)"})
+                 "traffic": traffic_tern if not quick else None, "bytes_per_weight": 9, "weights_per_call": n, "avg_call_ms": round(tq * 1e3, 4), "parity": "unpinned (no reference implementation)"})
     Wp, Wn = [torch.full((1,), 0.1, device=dev)], [torch.full((1,), 0.08, device=dev)]
     st = ops.tern_forward([w], "ttq", Wp=Wp, Wn=Wn)[0]["stats"]
     tb = event_time(lambda: ops.tern_backward([w], [gw], "ttq", stats=[st], Wp=Wp, Wn=Wn), 10)

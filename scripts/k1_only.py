@@ -18,3 +18,11 @@ for _ in range(5):
     ops.synth_backward_adam([p], [q], 4.0, [dW], [m1], [m2], [stp], 1e-2, wd=1e-3)
 torch.cuda.synchronize()
 print("rows", rows, "alg bytes fwd", rows * 132, "bwd", rows * 260, "bwd+adam", rows * 772)
+del m1, m2
+for _ in range(5):
+    ops.synth_forward([p], [q], 4.0, soft=False, codes=True)
+w = p.view(-1)
+for _ in range(5):
+    ops.tern_forward([w], "twn", decoded=False)
+print("codes-only alg bytes", rows * 133, "ternary quantise alg bytes", w.numel() * 9)
+torch.cuda.synchronize()
