@@ -30,6 +30,7 @@ namespace aq {
 constexpr int MAX_SEGS = 24;  // segments per launch (kernarg budget)
 constexpr int WAVES = 4;      // wavefronts per workgroup
 constexpr int ROWS_IT = 64;   // rows per wavefront iteration
+constexpr int STAGE_FLOATS = 260;  // LDS per wavefront for store_rows_staged: 256 floats of rows + the spill of the last ragged lane
 
 struct SegDev {
     const float *p, *q, *dW, *dss;
@@ -95,20 +96,68 @@ __device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, 
     }
 }
 
+// The 8 rows a lane group takes part in per batch: rows R0 + u * RPP + gq, u = 0..7.  With 16-byte-aligned rows (MEM != 0)
+// or in the tail of a tensor this is load_elems per row (row index clamped to the last row).  Otherwise (`fast`: every row of
+// the batch exists and at least 4 more rows follow it) each lane that owns part of a row issues ONE 16-byte access per row, also
+// the lane at the ragged row end, whose access runs up to 3 elements into the rows that follow; those elements are zeroed after
+// the load.  That is one memory instruction per row instead of four (a vector access for the full lanes plus three predicated
+// scalars for the ragged one), and no address clamping.
+template <int G, int MEM>
+__device__ __forceinline__ void load_rows8(const float *__restrict__ p, long long R0, long long rows, int L, int j, int gq, bool fast, float (&v)[8][4])
+{
+    constexpr int RPP = 64 / G;
+    if (MEM == 0 && fast) {
+        f4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (4 * j < L) {
+            const float *a = p + (R0 + gq) * (long long)L + 4 * j;
+            const long long step = (long long)RPP * L;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) __builtin_memcpy(&t[u], a + u * step, 16);
+        }
+        const bool k1 = 4 * j + 1 < L, k2 = 4 * j + 2 < L, k3 = 4 * j + 3 < L;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u][0] = t[u].x;
+            v[u][1] = k1 ? t[u].y : 0.0f;
+            v[u][2] = k2 ? t[u].z : 0.0f;
+            v[u][3] = k3 ? t[u].w : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long r = R0 + u * RPP + gq;
+            load_elems<G, MEM>(p, r < rows ? r : rows - 1, L, j, v[u]);
+        }
+    }
+}
+
 // Rows of L % 4 != 0 floats (124 bytes at L = 31) start at every 4-byte phase, so a lane's four elements are an
 // unaligned 16-byte access and the ragged row end takes predicated scalars; written that way the gradient
 // kernel reaches only 3.4 TB/s.  But the 64/G rows one instruction covers are CONTIGUOUS in memory and start
 // 16-byte aligned: the wavefront puts them into LDS in (row, element) order and takes them out as one flat
 // run of aligned 16-byte pieces, one store instruction for the whole run.  R0 = first row, nrows = valid rows
 // (uniform); buf = this wavefront's 256 floats of LDS; called by all lanes.
-template <int G>
+template <int G, bool FULL>  // FULL: all 64 / G rows present and their floats a multiple of 4 (no scalar tail)
 __device__ __forceinline__ void store_rows_staged(float *__restrict__ p, long long R0, int nrows, int L, int j, int gq, int lane, const float (&v)[4],
                                                   float *buf, bool stream)
 {
     __builtin_amdgcn_wave_barrier();  // (scheduling only: LDS operations of one wavefront execute in order)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (4 * j + k < L) buf[gq * L + 4 * j + k] = v[k];
+    // Four unpredicated 4-byte writes per lane, element 3 first: the lane at the ragged row end spills up to 3 values
+    // into the first elements of the next row, and the lane that owns those elements writes them with a LATER
+    // instruction (its element index is smaller), so the valid value is the one that stays.  Lanes beyond the row
+    // end take no part.  (buf has STAGE_FLOATS > 256 floats: the last row's spill stays inside it.)
+    if (4 * j < L) {
+        float *w = buf + gq * L + 4 * j;
+        w[3] = v[3];
+        __builtin_amdgcn_wave_barrier();
+        w[2] = v[2];
+        __builtin_amdgcn_wave_barrier();
+        w[1] = v[1];
+        __builtin_amdgcn_wave_barrier();
+        w[0] = v[0];
+    }
     __builtin_amdgcn_wave_barrier();
     const int nf = nrows * L;
     float *dst = p + R0 * (long long)L + 4 * lane;
@@ -116,7 +165,7 @@ __device__ __forceinline__ void store_rows_staged(float *__restrict__ p, long lo
         const f4 t = *reinterpret_cast<const f4 *>(buf + 4 * lane);
         if (stream) __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(dst));
         else *reinterpret_cast<f4 *>(dst) = t;
-    } else {
+    } else if (!FULL) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (4 * lane + k < nf) dst[k] = buf[4 * lane + k];
@@ -156,7 +205,7 @@ template <int G, int MEM, bool HARD, bool EXACT, bool CODES_ONLY = false>
 __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
 {
     constexpr int RPP = 64 / G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront-uniform: row ranges stay in scalar registers
     const int j = lane % G, gq = lane / G;
     const int si = find_segment(tab);
     const float *__restrict__ p = tab.s[si].p;
@@ -184,16 +233,13 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
     for (int it = 0; it < tab.K; ++it) {
         const long long row0 = row_begin + (long long)it * ROWS_IT;
         if (row0 >= rows) break;
+        const bool fast_rows = row0 + ROWS_IT + 4 <= rows;
         float myW = 0.0f;
         uint32_t myIdx = 0;
         static_for<G / 8>([&](auto UB) {
             constexpr int ub = 8 * decltype(UB)::value;
             float v[8][4];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long r = row0 + (ub + u) * RPP + gq;
-                load_elems<G, MEM>(p, r < rows ? r : rows - 1, L, j, v[u]);
-            }
+            load_rows8<G, MEM>(p, row0 + ub * RPP, rows, L, j, gq, fast_rows, v);
             // squared norms of the 8 rows; lane j == ub+u keeps row u's and inverts it once
             float my_ss = 1.0f;
 #pragma unroll
@@ -299,7 +345,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
 {
     constexpr int RPP = 64 / G;
     constexpr int LP = 4 * G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront-uniform: row ranges stay in scalar registers
     const int j = lane % G, gq = lane / G;
     const int si = find_segment(tab);
     const float *__restrict__ p = tab.s[si].p;
@@ -317,8 +363,8 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     float *__restrict__ part = tab.s[si].part;
     const long long rows = tab.s[si].rows;
     const int L = tab.s[si].L;
-    __shared__ __attribute__((aligned(16))) float stage_all[MEM == 0 ? WAVES * 256 : 4];
-    float *stage = stage_all + (MEM == 0 ? wave * 256 : 0);
+    __shared__ __attribute__((aligned(16))) float stage_all[MEM == 0 ? WAVES * STAGE_FLOATS : 4];
+    float *stage = stage_all + (MEM == 0 ? wave * STAGE_FLOATS : 0);
     const bool rag = MEM == 0 && tab.s[si].rag != 0;
     const bool rag_stream = tab.s[si].rag == 2;
 
@@ -338,96 +384,124 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     for (int it = 0; it < tab.K; ++it) {
         const long long row0 = row_begin + (long long)it * ROWS_IT;
         if (row0 >= rows) break;
-        static_for<G / 8>([&](auto UB) {
-            constexpr int ub = 8 * decltype(UB)::value;
-            float v[8][4];
-            float gw[8];
-            float m1[ADAM ? 8 : 1][4], m2[ADAM ? 8 : 1][4];
+        const bool fast_rows = row0 + ROWS_IT + 4 <= rows;
+        // FR = true: ragged rows leaving through LDS, and every row of the batch present (all but the last wavefronts of a
+        // layer): no row clamping, no per-row bounds, one 16-byte access per lane and row in both directions.
+        auto batch = [&](auto FR) {
+            constexpr bool FASTRAG = decltype(FR)::value;
+            static_for<G / 8>([&](auto UB) {
+                constexpr int ub = 8 * decltype(UB)::value;
+                float v[8][4];
+                float gw[8];
+                float m1[8][4], m2[8][4];  // (unused and removed by the compiler without ADAM)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long r = row0 + (ub + u) * RPP + gq;
-                const long long rc = r < rows ? r : rows - 1;
-                load_elems<G, MEM>(p, rc, L, j, v[u]);
-                gw[u] = dW ? dW[rc] : 0.0f;
-            }
-            if constexpr (ADAM) {
+                for (int u = 0; u < 8; ++u) gw[u] = 0.0f;
+                if (dW) {
+                    if (FASTRAG || fast_rows) {
+                        const float *g0 = dW + (row0 + ub * RPP + gq);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const long long r = row0 + (ub + u) * RPP + gq;
-                    const long long rc = r < rows ? r : rows - 1;
-                    load_elems<G, MEM>(am, rc, L, j, m1[u]);
-                    load_elems<G, MEM>(av, rc, L, j, m2[u]);
-                }
-            }
-            float my_ss = 1.0f;
+                        for (int u = 0; u < 8; ++u) gw[u] = g0[u * RPP];
+                    } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float ss = group_sum<G>(chain_sq(v[u]));
-                my_ss = (j == ub + u) ? ss : my_ss;
-            }
-            const float my_rn = inv_norm(my_ss);
-            static_for<8>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                const long long r = row0 + (ub + u) * RPP + gq;
-                const float rn = group_bcast<G, ub + u>(my_rn);
-                float pn[4], e[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    pn[k] = v[u][k] * rn;
-                    const float ex = EXACT ? expf_spec(beta * pn[k]) : exp2_hw(pn[k] * (beta * LOG2E));
-                    e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
-                }
-                const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
-                const float num = group_sum<G>(chain_dot(e, q4));
-                const float rden = 1.0f / den;
-                const float w = num * rden;
-                const float g = __builtin_fmaf(wds, w, gw[u]);
-                const float dot = g * w;
-                float s[4], gpn[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s[k] = e[k] * rden;
-                    const float gs = g * q4[k];
-                    gpn[k] = beta * (s[k] * (gs - dot));
-                }
-                const float dpn = group_sum<G>(chain_dot(pn, gpn));
-                float o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
-                float pn2[4], mo[4], vo[4];
-                if constexpr (ADAM) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        mo[k] = __builtin_fmaf(ad.omb1, o[k] - m1[u][k], m1[u][k]);
-                        vo[k] = __builtin_fmaf(ad.omb2 * o[k], o[k], ad.b2 * m2[u][k]);
-                        const float denom = __builtin_fmaf(sqrtf(vo[k]), rbc2, ad.eps);
-                        pn2[k] = v[u][k] - step_size * (mo[k] / denom);
-                    }
-                }
-                if (rag) {  // uniform: the rows of this instruction leave as one aligned run (all lanes take part)
-                    const long long R0 = row0 + (long long)(ub + u) * RPP;
-                    const int nrows = (int)(rows - R0 < RPP ? (rows - R0 > 0 ? rows - R0 : 0) : RPP);
-                    if (!ADAM || dp) store_rows_staged<G>(dp, R0, nrows, L, j, gq, lane, o, stage, rag_stream);
-                    if constexpr (ADAM) {
-                        store_rows_staged<G>(const_cast<float *>(p), R0, nrows, L, j, gq, lane, pn2, stage, rag_stream);
-                        store_rows_staged<G>(am, R0, nrows, L, j, gq, lane, mo, stage, rag_stream);
-                        store_rows_staged<G>(av, R0, nrows, L, j, gq, lane, vo, stage, rag_stream);
-                    }
-                }
-                if (r < rows) {
-                    if (!rag) {
-                        if (!ADAM || dp) store_elems<G, MEM>(dp, r, L, j, o);
-                        if constexpr (ADAM) {
-                            store_elems<G, MEM>(const_cast<float *>(p), r, L, j, pn2);
-                            store_elems<G, MEM>(am, r, L, j, mo);
-                            store_elems<G, MEM>(av, r, L, j, vo);
+                        for (int u = 0; u < 8; ++u) {
+                            const long long r = row0 + (ub + u) * RPP + gq;
+                            gw[u] = dW[r < rows ? r : rows - 1];
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
                 }
+                load_rows8<G, MEM>(p, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, v);
+                if constexpr (ADAM) {
+                    load_rows8<G, MEM>(am, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m1);
+                    load_rows8<G, MEM>(av, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m2);
+                }
+                float my_ss = 1.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float ss = group_sum<G>(chain_sq(v[u]));
+                    my_ss = (j == ub + u) ? ss : my_ss;
+                }
+                const float my_rn = inv_norm(my_ss);
+                static_for<8>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    const long long r = row0 + (ub + u) * RPP + gq;
+                    const float rn = group_bcast<G, ub + u>(my_rn);
+                    float pn[4], e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        pn[k] = v[u][k] * rn;
+                        const float ex = EXACT ? expf_spec(beta * pn[k]) : exp2_hw(pn[k] * (beta * LOG2E));
+                        e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
+                    }
+                    const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
+                    const float num = group_sum<G>(chain_dot(e, q4));
+                    const float rden = 1.0f / den;
+                    const float w = num * rden;
+                    const float g = __builtin_fmaf(wds, w, gw[u]);
+                    const float dot = g * w;
+                    float s[4], gpn[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s[k] = e[k] * rden;
+                        const float gs = g * q4[k];
+                        gpn[k] = beta * (s[k] * (gs - dot));
+                    }
+                    const float dpn = group_sum<G>(chain_dot(pn, gpn));
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(-pn[k], dpn, gpn[k]) * rn;
+                    float pn2[4], mo[4], vo[4];
+                    if constexpr (ADAM) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            mo[k] = __builtin_fmaf(ad.omb1, o[k] - m1[u][k], m1[u][k]);
+                            vo[k] = __builtin_fmaf(ad.omb2 * o[k], o[k], ad.b2 * m2[u][k]);
+                            const float denom = __builtin_fmaf(sqrtf(vo[k]), rbc2, ad.eps);
+                            pn2[k] = v[u][k] - step_size * (mo[k] / denom);
+                        }
+                    }
+                    if constexpr (FASTRAG) {
+                        const long long R0 = row0 + (long long)(ub + u) * RPP;
+                        if (!ADAM || dp) store_rows_staged<G, true>(dp, R0, RPP, L, j, gq, lane, o, stage, rag_stream);
+                        if constexpr (ADAM) {
+                            store_rows_staged<G, true>(const_cast<float *>(p), R0, RPP, L, j, gq, lane, pn2, stage, rag_stream);
+                            store_rows_staged<G, true>(am, R0, RPP, L, j, gq, lane, mo, stage, rag_stream);
+                            store_rows_staged<G, true>(av, R0, RPP, L, j, gq, lane, vo, stage, rag_stream);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                    } else {
+                        if (rag) {  // uniform: the rows of this instruction leave as one aligned run (all lanes take part)
+                            const long long R0 = row0 + (long long)(ub + u) * RPP;
+                            const int nrows = (int)(rows - R0 < RPP ? (rows - R0 > 0 ? rows - R0 : 0) : RPP);
+                            if (!ADAM || dp) store_rows_staged<G, false>(dp, R0, nrows, L, j, gq, lane, o, stage, rag_stream);
+                            if constexpr (ADAM) {
+                                store_rows_staged<G, false>(const_cast<float *>(p), R0, nrows, L, j, gq, lane, pn2, stage, rag_stream);
+                                store_rows_staged<G, false>(am, R0, nrows, L, j, gq, lane, mo, stage, rag_stream);
+                                store_rows_staged<G, false>(av, R0, nrows, L, j, gq, lane, vo, stage, rag_stream);
+                            }
+                        }
+                        if (r < rows) {
+                            if (!rag) {
+                                if (!ADAM || dp) store_elems<G, MEM>(dp, r, L, j, o);
+                                if constexpr (ADAM) {
+                                    store_elems<G, MEM>(const_cast<float *>(p), r, L, j, pn2);
+                                    store_elems<G, MEM>(am, r, L, j, mo);
+                                    store_elems<G, MEM>(av, r, L, j, vo);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                        }
+                    }
+                });
             });
-        });
+        };
+        if constexpr (MEM == 0) {
+            if (rag && fast_rows) batch(std::true_type{});
+            else batch(std::false_type{});
+        } else {
+            batch(std::false_type{});
+        }
     }
     if (part) {
 #pragma unroll
