@@ -544,6 +544,173 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
         }
 }
 
+// 3x3 convolutions with many channels: input channels a multiple of 16, 48 or more output channels; forward with
+// stride 1 | 2 and the stride-1 input gradient (MODE_DGRAD, the flipped kernel over dy).  Built for the matrix pipes:
+//  * k order inside a chunk of 16 input channels is (tap, channel): one k-block of 16 = one tap x 16 channels, and the four
+//    MFMAs of a k-block take channels 4*kq + t, t = 0..3, from lane group kq.
+//  * LDS image of the chunk: [pixel][channel], C3_CS = 20 floats per pixel (16 + 4 of padding), so the B fragments of the
+//    four MFMAs of a k-block are ONE 16-byte LDS read per lane, bank-conflict free over 16 neighbouring pixels
+//    (20 * x mod 64 are 16 distinct multiples of 4).  Two images: chunk c+1 is fetched into registers before the
+//    matrix work of chunk c and written to the other image after it; one barrier per chunk.
+//  * A fragments never touch LDS: for its output channel a lane needs W[row][4*kq + t][tap], t < 4, tap < 9, which is
+//    a contiguous run of 36 floats of the weight tensor (forward; 16-byte aligned), kept in registers for the whole
+//    chunk and fetched one chunk ahead.  The four wavefronts of a workgroup take 16 output channels each and share the
+//    image, so a workgroup covers 64 channels x 16*NT pixels.
+constexpr int C3_CS = 20;
+constexpr int C3_MAXIT = 6;  // staging items (pixel, group of 4 channels) per thread: 4 * plane <= 256 * C3_MAXIT
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jn = lane & 15, kq = lane >> 4;
+
+    int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int m0 = blockIdx.y * 64 + wave * 16;
+    const int bufsz = a.plane * C3_CS;
+    const int chs = a.IH * a.IW;
+    const float *img = a.in + (long long)n * a.KC * chs;
+
+    // staging: item i = (group of 4 channels cg, plane element e), cg-major so that neighbouring lanes read neighbouring
+    // pixels of one channel; goff = offset inside the chunk's 16 channel planes (-1: padding, -2: no item)
+    int goff[C3_MAXIT], loff[C3_MAXIT];
+    {
+        const int r0 = oy0 * a.rs - a.padT, c0 = ox0 * a.rs - a.padT;
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it) {
+            const int i = tid + 256 * it;
+            goff[it] = -2;
+            loff[it] = 0;
+            if (i < 4 * a.plane) {
+                const int cg = i / a.plane, e = i - cg * a.plane;
+                const int r = e / a.pitch, cc = e - r * a.pitch;
+                const int gy = r0 + r, gx = c0 + cc;
+                const bool ok = gy >= 0 && gx >= 0 && gy < a.IH && gx < a.IW;
+                goff[it] = ok ? 4 * cg * chs + gy * a.IW + gx : -1;
+                loff[it] = e * C3_CS + 4 * cg;
+            }
+        }
+    }
+    auto stage_load = [&](int cbase, f4 (&xr)[C3_MAXIT]) {
+        const float *src = img + (long long)cbase * chs;
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it) {
+            xr[it] = f4{0.f, 0.f, 0.f, 0.f};
+            if (goff[it] >= 0) {
+                const float *s0 = src + goff[it];
+                xr[it] = f4{s0[0], s0[chs], s0[2 * chs], s0[3 * chs]};
+            }
+        }
+    };
+    auto stage_store = [&](float *buf, const f4 (&xr)[C3_MAXIT]) {
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it)
+            if (goff[it] != -2) *reinterpret_cast<f4 *>(buf + loff[it]) = xr[it];
+    };
+
+    // A: 36 floats per lane and chunk.  Forward: W[row][cbase + 4*kq ..+3][0..8] is one aligned run; element (t, tap)
+    // sits at 9*t + tap.  Input gradient: row = input channel, W[cbase + 4*kq + t][row][0..8], four runs of 9, used
+    // with the tap flipped.
+    const int row = m0 + jn;
+    const bool rok = row < a.M;
+    auto load_a = [&](int cbase, float (&A)[36]) {
+        if (MODE == MODE_DGRAD) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *w = a.W + ((long long)(cbase + 4 * kq + t) * a.Cin + (rok ? row : 0)) * 9;
+                __builtin_memcpy(&A[9 * t], w, 16);
+                __builtin_memcpy(&A[9 * t + 4], w + 4, 16);
+                A[9 * t + 8] = w[8];
+            }
+        } else {
+            const float *w = a.W + (long long)(rok ? row : 0) * a.K + (long long)(cbase + 4 * kq) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const f4 v = *reinterpret_cast<const f4 *>(w + 4 * i);
+                A[4 * i] = v.x; A[4 * i + 1] = v.y; A[4 * i + 2] = v.z; A[4 * i + 3] = v.w;
+            }
+        }
+        if (!rok) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) A[i] = 0.0f;
+        }
+    };
+
+    int pb[NT], oyx[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int pr = 16 * t + jn;
+        const int py = pr / a.TW, px = pr - py * a.TW;
+        pb[t] = (py * a.rs * a.pitch + px * a.rs) * C3_CS + 4 * kq;
+        const int oy = oy0 + py, ox = ox0 + px;
+        oyx[t] = (oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
+    }
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = a.KC >> 4;
+    float A[36], An[36];
+    f4 xr[C3_MAXIT];
+    stage_load(0, xr);
+    load_a(0, A);
+    stage_store(smem, xr);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) {
+            stage_load(16 * (c + 1), xr);
+            load_a(16 * (c + 1), An);
+        }
+        const float *buf = smem + (c & 1) * bufsz;
+        f4 b[NT], bn[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                const int toff = (((tap + 1) / 3) * a.pitch + (tap + 1) % 3) * C3_CS;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
+            }
+            const int ta = MODE == MODE_DGRAD ? 8 - tap : tap;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[9 * t + ta], b[nt][t], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        }
+        if (more) stage_store(smem + ((c + 1) & 1) * bufsz, xr);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A[i] = An[i];
+    }
+
+    // D[row = 4*kq + r][col = jn]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (oyx[nt] < 0) continue;
+        const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = m0 + 4 * kq + r;
+            if (ch < a.M) {
+                const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
+                a.out[o] = a.res ? acc[nt][r] + a.res[o] : acc[nt][r];
+            }
+        }
+    }
+}
+
 // sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), the same bits in each of them
 __device__ __forceinline__ float row16_sum(float v)
 {
@@ -1735,6 +1902,48 @@ static int launch_chunked(ConvArgs &a, int N, hipStream_t st, const char *who)
     return check_launch(who);
 }
 
+// The many-channel 3x3 kernel (conv3x3_c16_kernel).  *taken = false: the shape is not one of its, nothing launched.
+template <int MODE>
+static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *taken)
+{
+    *taken = false;
+    if constexpr (MODE == MODE_FWD_CODES) return 0;
+    else {
+    if (a.ks != 3 || a.KC % 16 != 0 || a.M < 48 || a.dil != 1 || a.bn_on || a.stat_part || a.bwd_part) return 0;
+    if (MODE == MODE_FWD && (((uintptr_t)a.W & 15) != 0)) return 0;
+    if ((long long)a.IH * a.IW * 16 >= (1LL << 31)) return 0;
+    const int mgroups = (a.M + 63) / 64;
+    int NT = 8;
+    auto geom = [&](int nt, ConvArgs &g) {
+        pick_tile(g.OW, 16 * nt, g.TW, g.TH);
+        g.tiles_x = (g.OW + g.TW - 1) / g.TW;
+        g.tiles_y = (g.OH + g.TH - 1) / g.TH;
+        g.pitch = (g.TW - 1) * g.rs + 3;
+        g.rows_in = (g.TH - 1) * g.rs + 3;
+        g.plane = g.rows_in * g.pitch;
+    };
+    for (;; NT >>= 1) {
+        geom(NT, a);
+        const long long blocks = (long long)N * a.tiles_x * a.tiles_y * mgroups;
+        const bool fits = 4 * a.plane <= 256 * C3_MAXIT;
+        if (NT == 2 || (fits && blocks >= 512 && a.TH <= a.OH)) {
+            if (!fits) return 0;
+            break;
+        }
+    }
+    a.par = 0;
+    const long long gx = (long long)N * a.tiles_x * a.tiles_y;
+    if (gx >= (1LL << 31) || mgroups >= 65536) return 0;
+    const size_t lds = (size_t)2 * a.plane * C3_CS * 4;
+    dim3 grid((unsigned)gx, (unsigned)mgroups);
+    if (NT == 8) hipLaunchKernelGGL((conv3x3_c16_kernel<8, MODE>), grid, dim3(256), lds, st, a);
+    else if (NT == 4) hipLaunchKernelGGL((conv3x3_c16_kernel<4, MODE>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<2, MODE>), grid, dim3(256), lds, st, a);
+    *taken = true;
+    return check_launch(who);
+    }
+}
+
 // dry: no launch; returns 1 when the persistent kernel (the one that can normalise its input) would run
 // par: stride-2 dgrad by output parity classes (persistent kernel only); *fell = true when that kernel does not
 // take the shape, nothing launched (the caller then plans again without par)
@@ -1844,6 +2053,11 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
     AQ_REQUIRE(!a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
+    {
+        bool taken = false;
+        const int rc = launch_c3<MODE>(a, N, st, who, &taken);
+        if (taken) return rc;
+    }
     if (lds > 64 * 1024) return launch_chunked<MODE>(a, N, st, who);  // too many channels for one LDS image: chunks
     dim3 grid((unsigned)gx, gy);
 #define AQ_GEMM(MM, NN) hipLaunchKernelGGL((conv_gemm_kernel<MM, NN, MODE>), grid, dim3(256), lds, st, a)
@@ -1864,6 +2078,9 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         if (plan) *plan = ConvStatsPlan{};
         if (dry) return 0;
         AQ_REQUIRE(!a.bn_on && !a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no fused normalisation / statistics epilogue for this kernel size", who);
+        bool taken = false;
+        const int rc = launch_c3<MODE>(a, N, st, who, &taken);
+        if (taken) return rc;
         return launch_chunked<MODE>(a, N, st, who);
     }
     // stride-2 dgrad: by parity classes when the class shares of the k axis are whole pairs of k-blocks

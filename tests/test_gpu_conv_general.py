@@ -33,6 +33,10 @@ SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (70, 130, 3, 2, 1, 13, 9, 2),      # channel counts that are no multiples of 16
     (8, 8, 1, 1, 0, 5, 5, 3),
     (33, 17, 7, 1, 3, 12, 12, 1),
+    (32, 80, 3, 1, 0, 19, 23, 3),      # many-channel 3x3 kernel: no padding, 80 output channels (a ragged group of 64), odd sizes
+    (48, 48, 3, 1, 2, 9, 9, 2),        # ... padding 2
+    (16, 64, 3, 2, 1, 17, 15, 2),      # ... stride 2 on odd sizes
+    (64, 64, 3, 1, 1, 40, 40, 1),      # ... 32-pixel-wide tiles with a ragged last column of tiles
 ]
 
 
