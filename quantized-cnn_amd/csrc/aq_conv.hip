@@ -646,11 +646,12 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
     int pb[NT], oyx[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int pr = 16 * t + jn;
-        const int py = pr / a.TW, px = pr - py * a.TW;
+        const int pr = 16 * t + jn;  // (a tile of TH x TW pixels may leave the last of the 16 * NT slots empty)
+        const bool used = pr < a.TW * a.TH;
+        const int py = used ? pr / a.TW : 0, px = used ? pr - py * a.TW : 0;
         pb[t] = (py * a.rs * a.pitch + px * a.rs) * C3_CS + 4 * kq;
         const int oy = oy0 + py, ox = ox0 + px;
-        oyx[t] = (oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
+        oyx[t] = (used && oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
     }
 
     floatx4 acc[NT];
@@ -1780,6 +1781,161 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJo
     wgrad_reduce_block(t.part[j], t.dW[j], t.n[j], t.nslab[j], blockIdx.x - t.first[j]);
 }
 
+// Weight gradient of 3x3 convolutions with many channels (input channels a multiple of 32, output channels a multiple of
+// 16 and at least 48), stride S.  GEMM view: dW[co][(ci, tap)] = sum over pixels of dy[co][pixel] * x[ci][pixel shifted by
+// the tap]; k = pixels.  A workgroup owns 64 output channels x 32 input channels x 9 taps (wavefront w: channels 16w ..
+// 16w+15, 18 accumulator tiles) and a slab of the pixel tiles (TH full rows of one image each); slabs are summed by
+// wgrad_reduce.  Both operands sit in LDS as [pixel][channel] with pitches of 68 (dy) and 36 (x) floats: the lanes of an
+// MFMA operand read (channel jn, pixel group kq) hit banks jn + 16 * kq, no conflicts, with plain 4-byte reads at any
+// tap shift.  Rows of the dy tile are padded to a multiple of 4 pixels (zeros), so the 4 pixels of a lane's k-group
+// stay in one row and the x image is addressed as base + tap + t * S pixels.  The next tile is fetched into registers
+// while the matrix work of the current one runs.
+constexpr int WC_CSA = 68, WC_CSX = 36;
+constexpr int WC_MAXA = 8, WC_MAXX = 10;  // staging items per thread: 16 * slots <= 256 * MAXA, 8 * image pixels <= 256 * MAXX
+struct WgC16Args {
+    const float *x, *dy;
+    float *part;
+    int N, Cin, H, Wd, Cout, Ho, Wo, pad;
+    int TH, PW4, tiles_y, ntiles, nslab;
+    int XR, XP, nkb, nW;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int nslots = a.nkb * 16;
+    float *dyS = smem;                       // [nslots][68]
+    float *xS = smem + nslots * WC_CSA;      // [XR * XP][36]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jn = lane & 15, kq = lane >> 4;
+    const int slab = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 32;
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.Wd, npx = a.XR * a.XP;
+
+    // staging items.  dy: (slot p, group of 4 channels), p-major inside a group; x: (image pixel e, group of 4 channels)
+    int relA[WC_MAXA], locA[WC_MAXA];  // locA = (row << 16) | LDS offset; relA < 0: zero (padding column / channel beyond Cout)
+    int relX[WC_MAXX], locX[WC_MAXX];  // relX: INT_MIN = no item, otherwise offset from the tile's first image row; locX = (row << 16) | offset | colbad << 15
+#pragma unroll
+    for (int it = 0; it < WC_MAXA; ++it) {
+        const int i = tid + 256 * it;
+        relA[it] = -1;
+        locA[it] = -1;
+        if (i < 16 * nslots) {
+            const int cg = i / nslots, p = i - cg * nslots;
+            const int py = p / a.PW4, px = p - py * a.PW4;
+            const bool ok = px < a.Wo && py < a.TH && co0 + 4 * cg < a.Cout;
+            relA[it] = ok ? 4 * cg * HoWo + py * a.Wo + px : -1;
+            locA[it] = (py << 16) | (p * WC_CSA + 4 * cg);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < WC_MAXX; ++it) {
+        const int i = tid + 256 * it;
+        relX[it] = 0;
+        locX[it] = -1;
+        if (i < 8 * npx) {
+            const int cg = i / npx, e = i - cg * npx;
+            const int r = e / a.XP, c = e - r * a.XP;
+            const int gx = c - a.pad;
+            const bool colok = gx >= 0 && gx < a.Wd;
+            relX[it] = 4 * cg * HW + r * a.Wd + gx;
+            locX[it] = (r << 16) | (colok ? 0 : 0x8000) | (e * WC_CSX + 4 * cg);
+        }
+    }
+    auto tile_coords = [&](int tile, int &n, int &ty) {
+        n = tile / a.tiles_y;
+        ty = tile - n * a.tiles_y;
+    };
+    auto stage_load = [&](int tile, f4 (&ra)[WC_MAXA], f4 (&rx)[WC_MAXX]) {
+        int n, ty;
+        tile_coords(tile, n, ty);
+        const int rows_left = a.Ho - ty * a.TH;
+        const float *da = a.dy + ((long long)n * a.Cout + co0) * HoWo + (long long)ty * a.TH * a.Wo;
+#pragma unroll
+        for (int it = 0; it < WC_MAXA; ++it) {
+            ra[it] = f4{0.f, 0.f, 0.f, 0.f};
+            if (relA[it] >= 0 && (locA[it] >> 16) < rows_left) {
+                const float *s0 = da + relA[it];
+                ra[it] = f4{s0[0], s0[HoWo], s0[2 * HoWo], s0[3 * HoWo]};
+            }
+        }
+        const int gy0 = ty * a.TH * S - a.pad;  // image row of the x image's first row
+        const float *dx = a.x + ((long long)n * a.Cin + ci0) * HW + (long long)gy0 * a.Wd;
+#pragma unroll
+        for (int it = 0; it < WC_MAXX; ++it) {
+            rx[it] = f4{0.f, 0.f, 0.f, 0.f};
+            const int gy = gy0 + (locX[it] >> 16);
+            if (locX[it] >= 0 && !(locX[it] & 0x8000) && gy >= 0 && gy < a.H) {
+                const float *s0 = dx + relX[it];
+                rx[it] = f4{s0[0], s0[HW], s0[2 * HW], s0[3 * HW]};
+            }
+        }
+    };
+    auto stage_store = [&](const f4 (&ra)[WC_MAXA], const f4 (&rx)[WC_MAXX]) {
+#pragma unroll
+        for (int it = 0; it < WC_MAXA; ++it)
+            if (locA[it] >= 0) *reinterpret_cast<f4 *>(dyS + (locA[it] & 0x7fff)) = ra[it];
+#pragma unroll
+        for (int it = 0; it < WC_MAXX; ++it)
+            if (locX[it] >= 0) *reinterpret_cast<f4 *>(xS + (locX[it] & 0x7fff)) = rx[it];
+    };
+
+    floatx4 acc[2][9];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[g][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // tiles of this slab: [t0, t1)
+    const int t0 = (int)((long long)slab * a.ntiles / a.nslab), t1 = (int)((long long)(slab + 1) * a.ntiles / a.nslab);
+    f4 ra[WC_MAXA], rx[WC_MAXX];
+    if (t0 < t1) {
+        stage_load(t0, ra, rx);
+        stage_store(ra, rx);
+    }
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const bool more = tile + 1 < t1;
+        if (more) stage_load(tile + 1, ra, rx);
+        for (int kb = 0; kb < a.nkb; ++kb) {
+            const int p = 16 * kb + 4 * kq;
+            const int py = p / a.PW4, px = p - py * a.PW4;
+            const float *ap = dyS + p * WC_CSA + wave * 16 + jn;
+            const float *bp = xS + (py < a.TH ? (py * S * a.XP + px * S) * WC_CSX : 0) + jn;
+            float av[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t] = ap[t * WC_CSA];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float *bt = bp + ((tap / 3) * a.XP + tap % 3) * WC_CSX + t * S * WC_CSX;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[g][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bt[16 * g], acc[g][tap], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            stage_store(ra, rx);
+            __syncthreads();
+        }
+    }
+
+    // D[row = 4*kq + r -> co][col = jn -> ci]
+    float *out = a.part + (long long)slab * a.nW;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wave * 16 + 4 * kq + r, ci = ci0 + 16 * g + jn;
+                if (co < a.Cout) out[((long long)co * a.Cin + ci) * 9 + tap] = acc[g][tap][r];
+            }
+}
+
 // ------------------------------------------------------------------------------------- host side
 
 // 3x3 / padding 1 is the reference's only configuration (adp_qtz_fan.py:574-601 is written for any ksize / stride /
@@ -1913,32 +2069,49 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
     if (MODE == MODE_FWD && (((uintptr_t)a.W & 15) != 0)) return 0;
     if ((long long)a.IH * a.IW * 16 >= (1LL << 31)) return 0;
     const int mgroups = (a.M + 63) / 64;
-    int NT = 8;
-    auto geom = [&](int nt, ConvArgs &g) {
-        pick_tile(g.OW, 16 * nt, g.TW, g.TH);
-        g.tiles_x = (g.OW + g.TW - 1) / g.TW;
-        g.tiles_y = (g.OH + g.TH - 1) / g.TH;
-        g.pitch = (g.TW - 1) * g.rs + 3;
-        g.rows_in = (g.TH - 1) * g.rs + 3;
-        g.plane = g.rows_in * g.pitch;
-    };
-    for (;; NT >>= 1) {
-        geom(NT, a);
-        const long long blocks = (long long)N * a.tiles_x * a.tiles_y * mgroups;
-        const bool fits = 4 * a.plane <= 256 * C3_MAXIT;
-        if (NT == 2 || (fits && blocks >= 512 && a.TH <= a.OH)) {
-            if (!fits) return 0;
-            break;
+    // tile = TH x TW output pixels in 16 * NT slots.  Candidates: full-width rows (no ragged last column) or 32 / 16 / 8
+    // columns, NT = 2 .. 8; the choice maximises (share of slots that hold a pixel) x (share of the chip's 512
+    // workgroup places that the last round of workgroups fills), with a slight preference for larger tiles.
+    int NT = 0;
+    double best = 0.0;
+    const int tws[4] = {a.OW <= 64 ? a.OW : 0, 32, 16, 8};
+    for (int ti = 0; ti < 4; ++ti) {
+        const int tw = tws[ti];
+        if (tw <= 0 || (ti > 0 && tw >= 2 * a.OW)) continue;
+        for (int nt = 8; nt >= 2; --nt) {
+            int th = std::min(16 * nt / tw, a.OH);
+            if (th < 1) continue;
+            const int plane = ((th - 1) * a.rs + 3) * ((tw - 1) * a.rs + 3);
+            if (4 * plane > 256 * C3_MAXIT) continue;
+            const long long tiles = (long long)((a.OW + tw - 1) / tw) * ((a.OH + th - 1) / th);
+            const long long blocks = (long long)N * tiles * mgroups;
+            const double util = (double)a.OW * a.OH / ((double)tiles * 16 * nt);
+            const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+            const double score = util * fill * (1.0 - 0.015 * (8 - nt));
+            if (score > best) {
+                best = score;
+                NT = nt;
+                a.TW = tw;
+                a.TH = th;
+            }
         }
     }
+    if (NT == 0) return 0;
+    a.tiles_x = (a.OW + a.TW - 1) / a.TW;
+    a.tiles_y = (a.OH + a.TH - 1) / a.TH;
+    a.pitch = (a.TW - 1) * a.rs + 3;
+    a.rows_in = (a.TH - 1) * a.rs + 3;
+    a.plane = a.rows_in * a.pitch;
     a.par = 0;
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     if (gx >= (1LL << 31) || mgroups >= 65536) return 0;
     const size_t lds = (size_t)2 * a.plane * C3_CS * 4;
     dim3 grid((unsigned)gx, (unsigned)mgroups);
-    if (NT == 8) hipLaunchKernelGGL((conv3x3_c16_kernel<8, MODE>), grid, dim3(256), lds, st, a);
-    else if (NT == 4) hipLaunchKernelGGL((conv3x3_c16_kernel<4, MODE>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_c16_kernel<2, MODE>), grid, dim3(256), lds, st, a);
+    switch (NT) {
+#define AQ_C3(NN) case NN: hipLaunchKernelGGL((conv3x3_c16_kernel<NN, MODE>), grid, dim3(256), lds, st, a); break;
+        AQ_C3(2) AQ_C3(3) AQ_C3(4) AQ_C3(5) AQ_C3(6) AQ_C3(7) AQ_C3(8)
+#undef AQ_C3
+    }
     *taken = true;
     return check_launch(who);
     }
@@ -2446,12 +2619,64 @@ static WgradBigPlan wgrad_big_plan(aq::WgradArgs &a)
     return p;
 }
 
+// Plan of conv_wgrad_c16_kernel (3x3, input channels a multiple of 32, output channels a multiple of 16 and >= 48).
+struct WgC16Plan {
+    bool use;
+    aq::WgC16Args a;
+    dim3 grid;
+    size_t lds, ws_bytes;
+};
+static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad)
+{
+    using namespace aq;
+    WgC16Plan p = {};
+    if (ks != 3 || Cin % 32 != 0 || Cout % 16 != 0 || Cout < 48 || N < 1) return p;
+    WgC16Args &a = p.a;
+    a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.pad = pad;
+    a.Ho = conv_out(H, 3, stride, pad);
+    a.Wo = conv_out(Wd, 3, stride, pad);
+    if ((long long)Cin * H * Wd >= (1LL << 29) || (long long)Cout * a.Ho * a.Wo >= (1LL << 29) || H >= 32768) return p;
+    a.PW4 = (a.Wo + 3) & ~3;
+    a.XP = (a.PW4 - 1) * stride + 3;
+    // rows per tile: at most 128 pixel slots, the x image within its staging and LDS budget; best slot utilisation wins
+    double best = 0.0;
+    for (int th = 1; th <= a.Ho && th * a.PW4 <= 128; ++th) {
+        const int xr = (th - 1) * stride + 3;
+        if (8 * xr * a.XP > 256 * WC_MAXX || xr * a.XP > 300) break;
+        const int nkb = (th * a.PW4 + 15) / 16, ty = (a.Ho + th - 1) / th;
+        const double util = (double)a.Ho * a.Wo / ((double)ty * nkb * 16) * (1.0 - 0.2 / nkb);  // (fixed cost per tile: barriers, staging)
+        if (util > best) {
+            best = util;
+            a.TH = th;
+        }
+    }
+    if (a.TH == 0) return p;
+    a.XR = (a.TH - 1) * stride + 3;
+    a.nkb = (a.TH * a.PW4 + 15) / 16;
+    a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
+    a.ntiles = N * a.tiles_y;
+    a.nW = Cout * Cin * 9;
+    const int gy = (Cout + 63) / 64, gz = Cin / 32;
+    if (gy >= 65536 || gz >= 65536) return p;
+    // slabs: about two rounds of workgroups over the chip's 512 places, at least 2 tiles per slab, at most 256 slabs
+    long long want = (1024 + (long long)gy * gz - 1) / ((long long)gy * gz);
+    want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (a.ntiles + 1) / 2));
+    a.nslab = (int)std::min<long long>(want, a.ntiles);
+    p.grid = dim3((unsigned)a.nslab, (unsigned)gy, (unsigned)gz);
+    p.lds = ((size_t)a.nkb * 16 * WC_CSA + (size_t)a.XR * a.XP * WC_CSX) * 4;
+    p.ws_bytes = (size_t)a.nslab * a.nW * 4;
+    p.use = true;
+    return p;
+}
+
 size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
 {
     if (aq::check_conv("aq_conv_wgrad_workspace_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     aq::WgradArgs a = {};
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ksize; a.pad = pad;
     {
+        const WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ksize, stride, pad);
+        if (cp.use) return cp.ws_bytes;
         aq::WgradArgs b = a;
         const WgradBigPlan bp = wgrad_big_plan(b);
         if (bp.use) return bp.ws_bytes;
@@ -2604,6 +2829,23 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
     if (!bn) {
+        WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad);
+        if (cp.use) {
+            AQ_REQUIRE(workspace && workspace_bytes >= cp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", cp.ws_bytes,
+                       workspace_bytes);
+            cp.a.x = x; cp.a.dy = dy; cp.a.part = static_cast<float *>(workspace);
+            if (stride == 1) {
+                auto kern = conv_wgrad_c16_kernel<1>;
+                if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds);
+                hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);
+            } else {
+                auto kern = conv_wgrad_c16_kernel<2>;
+                if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds);
+                hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);
+            }
+            *nslab_out = cp.a.nslab;
+            return check_launch("aq_conv_wgrad");
+        }
         WgradArgs b = a;
         const WgradBigPlan bp = wgrad_big_plan(b);
         if (bp.use) {

@@ -37,6 +37,9 @@ SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (48, 48, 3, 1, 2, 9, 9, 2),        # ... padding 2
     (16, 64, 3, 2, 1, 17, 15, 2),      # ... stride 2 on odd sizes
     (64, 64, 3, 1, 1, 40, 40, 1),      # ... 32-pixel-wide tiles with a ragged last column of tiles
+    (64, 64, 3, 2, 2, 12, 10, 2),      # many-channel weight-gradient kernel: stride 2 with padding 2
+    (32, 48, 3, 1, 1, 7, 7, 5),        # ... whole 7 x 7 images per tile, rows padded to 8 pixels, 48 output channels
+    (64, 80, 3, 2, 1, 17, 15, 3),      # ... stride 2 on odd sizes, a ragged group of output channels
 ]
 
 
