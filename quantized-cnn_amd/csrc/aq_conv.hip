@@ -1791,6 +1791,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJo
 // stay in one row and the x image is addressed as base + tap + t * S pixels.  The next tile is fetched into registers
 // while the matrix work of the current one runs.
 constexpr int WC_CSA = 68, WC_CSX = 36;
+constexpr int WC_TP = 292;  // LDS pitch of the 288-float rows of the finished dW tile
 constexpr int WC_MAXA = 8, WC_MAXX = 10;  // staging items per thread: 16 * slots <= 256 * MAXA, 8 * image pixels <= 256 * MAXX
 struct WgC16Args {
     const float *x, *dy;
@@ -1923,17 +1924,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         }
     }
 
-    // D[row = 4*kq + r -> co][col = jn -> ci]
-    float *out = a.part + (long long)slab * a.nW;
+    // D[row = 4*kq + r -> co][col = jn -> ci]: through LDS, so that the slab is written as whole 1152-byte rows
+    // (output channel co: 32 input channels x 9 taps are contiguous in dW) with 16-byte stores
+    float *tileS = smem;  // [64][WC_TP]
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wave * 16 + 4 * kq + r, ci = ci0 + 16 * g + jn;
-                if (co < a.Cout) out[((long long)co * a.Cin + ci) * 9 + tap] = acc[g][tap][r];
-            }
+            for (int r = 0; r < 4; ++r) tileS[(wave * 16 + 4 * kq + r) * WC_TP + (16 * g + jn) * 9 + tap] = acc[g][tap][r];
+    __syncthreads();
+    float *out = a.part + (long long)slab * a.nW + (long long)ci0 * 9;
+    for (int i = tid; i < 64 * 72; i += 256) {
+        const int r = i / 72, c = i - 72 * r;
+        if (co0 + r < a.Cout)
+            *reinterpret_cast<f4 *>(out + (long long)(co0 + r) * a.Cin * 9 + 4 * c) = *reinterpret_cast<const f4 *>(tileS + r * WC_TP + 4 * c);
+    }
 }
 
 // ------------------------------------------------------------------------------------- host side
@@ -2658,12 +2664,13 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     a.nW = Cout * Cin * 9;
     const int gy = (Cout + 63) / 64, gz = Cin / 32;
     if (gy >= 65536 || gz >= 65536) return p;
-    // slabs: about two rounds of workgroups over the chip's 512 places, at least 2 tiles per slab, at most 256 slabs
-    long long want = (1024 + (long long)gy * gz - 1) / ((long long)gy * gz);
+    // slabs: one round of workgroups over the chip's 512 places (every slab costs a pass over dW), at least 2 tiles per
+    // slab, at most 256 slabs
+    long long want = (512 + (long long)gy * gz - 1) / ((long long)gy * gz);
     want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (a.ntiles + 1) / 2));
     a.nslab = (int)std::min<long long>(want, a.ntiles);
     p.grid = dim3((unsigned)a.nslab, (unsigned)gy, (unsigned)gz);
-    p.lds = ((size_t)a.nkb * 16 * WC_CSA + (size_t)a.XR * a.XP * WC_CSX) * 4;
+    p.lds = std::max(((size_t)a.nkb * 16 * WC_CSA + (size_t)a.XR * a.XP * WC_CSX) * 4, (size_t)64 * WC_TP * 4);
     p.ws_bytes = (size_t)a.nslab * a.nW * 4;
     p.use = true;
     return p;
