@@ -1790,9 +1790,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJo
 // tap shift.  Rows of the dy tile are padded to a multiple of 4 pixels (zeros), so the 4 pixels of a lane's k-group
 // stay in one row and the x image is addressed as base + tap + t * S pixels.  The next tile is fetched into registers
 // while the matrix work of the current one runs.
-constexpr int WC_CSA = 68, WC_CSX = 36;
-constexpr int WC_TP = 292;  // LDS pitch of the 288-float rows of the finished dW tile
-constexpr int WC_MAXA = 8, WC_MAXX = 10;  // staging items per thread: 16 * slots <= 256 * MAXA, 8 * image pixels <= 256 * MAXX
+constexpr int WC_CSA = 68;
+constexpr int WC_MAXA = 8;  // dy staging items per thread: 16 * slots <= 256 * WC_MAXA
 struct WgC16Args {
     const float *x, *dy;
     float *part;
@@ -1801,23 +1800,29 @@ struct WgC16Args {
     int XR, XP, nkb, nW;
 };
 
-template <int S>
+// S = stride, KS = 3 | 1 (kernel size), NG = groups of 16 input channels per workgroup (KS = 3: 2, KS = 1: 4).
+// KS = 1 (the projections of dimension-changing blocks): no taps, so x is staged like dy, one pixel per slot (only the
+// pixels the stride keeps), and the workgroup takes 64 input channels instead of 32.
+template <int S, int KS, int NG>
 __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
 {
+    constexpr int T2 = KS * KS, CSX = 16 * NG + 4, CGX = 4 * NG, ROW = 16 * NG * T2, TP = ROW + 4;
+    constexpr int MAXX = KS == 1 ? 8 : 10;  // x staging items per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int nslots = a.nkb * 16;
     float *dyS = smem;                       // [nslots][68]
-    float *xS = smem + nslots * WC_CSA;      // [XR * XP][36]
+    float *xS = smem + nslots * WC_CSA;      // KS = 3: [XR * XP][CSX]; KS = 1: [nslots][CSX]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jn = lane & 15, kq = lane >> 4;
-    const int slab = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 32;
-    const int HoWo = a.Ho * a.Wo, HW = a.H * a.Wd, npx = a.XR * a.XP;
+    const int slab = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 16 * NG;
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.Wd, npx = KS == 1 ? nslots : a.XR * a.XP;
 
-    // staging items.  dy: (slot p, group of 4 channels), p-major inside a group; x: (image pixel e, group of 4 channels)
-    int relA[WC_MAXA], locA[WC_MAXA];  // locA = (row << 16) | LDS offset; relA < 0: zero (padding column / channel beyond Cout)
-    int relX[WC_MAXX], locX[WC_MAXX];  // relX: INT_MIN = no item, otherwise offset from the tile's first image row; locX = (row << 16) | offset | colbad << 15
+    // staging items.  dy: (slot p, group of 4 channels), p-major inside a group; x: (image pixel or slot, group of 4 channels).
+    // loc = (row << 16) | [bit 15: column outside the image] | LDS offset, -1 = no item; rel = offset from the tile's first row
+    int relA[WC_MAXA], locA[WC_MAXA];
+    int relX[MAXX], locX[MAXX];
 #pragma unroll
     for (int it = 0; it < WC_MAXA; ++it) {
         const int i = tid + 256 * it;
@@ -1832,26 +1837,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         }
     }
 #pragma unroll
-    for (int it = 0; it < WC_MAXX; ++it) {
+    for (int it = 0; it < MAXX; ++it) {
         const int i = tid + 256 * it;
         relX[it] = 0;
         locX[it] = -1;
-        if (i < 8 * npx) {
+        if (i < CGX * npx) {
             const int cg = i / npx, e = i - cg * npx;
-            const int r = e / a.XP, c = e - r * a.XP;
-            const int gx = c - a.pad;
-            const bool colok = gx >= 0 && gx < a.Wd;
-            relX[it] = 4 * cg * HW + r * a.Wd + gx;
-            locX[it] = (r << 16) | (colok ? 0 : 0x8000) | (e * WC_CSX + 4 * cg);
+            if (KS == 1) {
+                const int py = e / a.PW4, px = e - py * a.PW4;
+                const bool ok = px < a.Wo && py < a.TH;
+                relX[it] = 4 * cg * HW + py * S * a.Wd + px * S;
+                locX[it] = (py << 16) | (ok ? 0 : 0x8000) | (e * CSX + 4 * cg);
+            } else {
+                const int r = e / a.XP, c = e - r * a.XP;
+                const int gx = c - a.pad;
+                const bool colok = gx >= 0 && gx < a.Wd;
+                relX[it] = 4 * cg * HW + r * a.Wd + gx;
+                locX[it] = (r << 16) | (colok ? 0 : 0x8000) | (e * CSX + 4 * cg);
+            }
         }
     }
-    auto tile_coords = [&](int tile, int &n, int &ty) {
-        n = tile / a.tiles_y;
-        ty = tile - n * a.tiles_y;
-    };
-    auto stage_load = [&](int tile, f4 (&ra)[WC_MAXA], f4 (&rx)[WC_MAXX]) {
-        int n, ty;
-        tile_coords(tile, n, ty);
+    auto stage_load = [&](int tile, f4 (&ra)[WC_MAXA], f4 (&rx)[MAXX]) {
+        const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
         const int rows_left = a.Ho - ty * a.TH;
         const float *da = a.dy + ((long long)n * a.Cout + co0) * HoWo + (long long)ty * a.TH * a.Wo;
 #pragma unroll
@@ -1862,36 +1869,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
                 ra[it] = f4{s0[0], s0[HoWo], s0[2 * HoWo], s0[3 * HoWo]};
             }
         }
-        const int gy0 = ty * a.TH * S - a.pad;  // image row of the x image's first row
+        // KS = 3: image row of the x image's first row (may lie above the image); KS = 1: the tile's first kept row
+        const int gy0 = ty * a.TH * S - (KS == 1 ? 0 : a.pad);
         const float *dx = a.x + ((long long)n * a.Cin + ci0) * HW + (long long)gy0 * a.Wd;
 #pragma unroll
-        for (int it = 0; it < WC_MAXX; ++it) {
+        for (int it = 0; it < MAXX; ++it) {
             rx[it] = f4{0.f, 0.f, 0.f, 0.f};
-            const int gy = gy0 + (locX[it] >> 16);
-            if (locX[it] >= 0 && !(locX[it] & 0x8000) && gy >= 0 && gy < a.H) {
+            const int row = locX[it] >> 16;
+            const bool rowok = KS == 1 ? row < rows_left : (gy0 + row >= 0 && gy0 + row < a.H);
+            if (locX[it] >= 0 && !(locX[it] & 0x8000) && rowok) {
                 const float *s0 = dx + relX[it];
                 rx[it] = f4{s0[0], s0[HW], s0[2 * HW], s0[3 * HW]};
             }
         }
     };
-    auto stage_store = [&](const f4 (&ra)[WC_MAXA], const f4 (&rx)[WC_MAXX]) {
+    auto stage_store = [&](const f4 (&ra)[WC_MAXA], const f4 (&rx)[MAXX]) {
 #pragma unroll
         for (int it = 0; it < WC_MAXA; ++it)
             if (locA[it] >= 0) *reinterpret_cast<f4 *>(dyS + (locA[it] & 0x7fff)) = ra[it];
 #pragma unroll
-        for (int it = 0; it < WC_MAXX; ++it)
+        for (int it = 0; it < MAXX; ++it)
             if (locX[it] >= 0) *reinterpret_cast<f4 *>(xS + (locX[it] & 0x7fff)) = rx[it];
     };
 
-    floatx4 acc[2][9];
+    floatx4 acc[NG][T2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[g][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T2; ++t) acc[g][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // tiles of this slab: [t0, t1)
     const int t0 = (int)((long long)slab * a.ntiles / a.nslab), t1 = (int)((long long)(slab + 1) * a.ntiles / a.nslab);
-    f4 ra[WC_MAXA], rx[WC_MAXX];
+    f4 ra[WC_MAXA], rx[MAXX];
     if (t0 < t1) {
         stage_load(t0, ra, rx);
         stage_store(ra, rx);
@@ -1902,19 +1911,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         if (more) stage_load(tile + 1, ra, rx);
         for (int kb = 0; kb < a.nkb; ++kb) {
             const int p = 16 * kb + 4 * kq;
-            const int py = p / a.PW4, px = p - py * a.PW4;
             const float *ap = dyS + p * WC_CSA + wave * 16 + jn;
-            const float *bp = xS + (py < a.TH ? (py * S * a.XP + px * S) * WC_CSX : 0) + jn;
+            const float *bp;
+            if (KS == 1) {
+                bp = xS + p * CSX + jn;
+            } else {
+                const int py = p / a.PW4, px = p - py * a.PW4;
+                bp = xS + (py < a.TH ? (py * S * a.XP + px * S) * CSX : 0) + jn;
+            }
             float av[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) av[t] = ap[t * WC_CSA];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float *bt = bp + ((tap / 3) * a.XP + tap % 3) * WC_CSX + t * S * WC_CSX;
+                for (int tap = 0; tap < T2; ++tap) {
+                    const float *bt = KS == 1 ? bp + t * CSX : bp + ((tap / 3) * a.XP + tap % 3) * CSX + t * S * CSX;
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bt[16 * g], acc[g][tap], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bt[16 * g], acc[g][tap], 0, 0, 0);
                 }
         }
         __syncthreads();
@@ -1924,21 +1938,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         }
     }
 
-    // D[row = 4*kq + r -> co][col = jn -> ci]: through LDS, so that the slab is written as whole 1152-byte rows
-    // (output channel co: 32 input channels x 9 taps are contiguous in dW) with 16-byte stores
-    float *tileS = smem;  // [64][WC_TP]
+    // D[row = 4*kq + r -> co][col = jn -> ci]: through LDS, so that the slab is written as whole rows (output channel
+    // co: the workgroup's input channels x taps are contiguous in dW) with 16-byte stores
+    float *tileS = smem;  // [64][TP]
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < T2; ++tap)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tileS[(wave * 16 + 4 * kq + r) * WC_TP + (16 * g + jn) * 9 + tap] = acc[g][tap][r];
+            for (int r = 0; r < 4; ++r) tileS[(wave * 16 + 4 * kq + r) * TP + (16 * g + jn) * T2 + tap] = acc[g][tap][r];
     __syncthreads();
-    float *out = a.part + (long long)slab * a.nW + (long long)ci0 * 9;
-    for (int i = tid; i < 64 * 72; i += 256) {
-        const int r = i / 72, c = i - 72 * r;
+    float *out = a.part + (long long)slab * a.nW + (long long)ci0 * T2;
+    for (int i = tid; i < 64 * (ROW / 4); i += 256) {
+        const int r = i / (ROW / 4), c = i - (ROW / 4) * r;
         if (co0 + r < a.Cout)
-            *reinterpret_cast<f4 *>(out + (long long)(co0 + r) * a.Cin * 9 + 4 * c) = *reinterpret_cast<const f4 *>(tileS + r * WC_TP + 4 * c);
+            *reinterpret_cast<f4 *>(out + (long long)(co0 + r) * a.Cin * T2 + 4 * c) = *reinterpret_cast<const f4 *>(tileS + r * TP + 4 * c);
     }
 }
 
@@ -2636,19 +2650,21 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
 {
     using namespace aq;
     WgC16Plan p = {};
-    if (ks != 3 || Cin % 32 != 0 || Cout % 16 != 0 || Cout < 48 || N < 1) return p;
+    if (!(ks == 3 && Cin % 32 == 0) && !(ks == 1 && Cin % 64 == 0 && pad == 0)) return p;
+    if (Cout % 16 != 0 || Cout < 48 || N < 1) return p;
+    const int NG = ks == 3 ? 2 : 4, CSX = 16 * NG + 4, row = 16 * NG * ks * ks;
     WgC16Args &a = p.a;
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.pad = pad;
-    a.Ho = conv_out(H, 3, stride, pad);
-    a.Wo = conv_out(Wd, 3, stride, pad);
+    a.Ho = conv_out(H, ks, stride, pad);
+    a.Wo = conv_out(Wd, ks, stride, pad);
     if ((long long)Cin * H * Wd >= (1LL << 29) || (long long)Cout * a.Ho * a.Wo >= (1LL << 29) || H >= 32768) return p;
     a.PW4 = (a.Wo + 3) & ~3;
-    a.XP = (a.PW4 - 1) * stride + 3;
+    a.XP = (a.PW4 - 1) * stride + ks;
     // rows per tile: at most 128 pixel slots, the x image within its staging and LDS budget; best slot utilisation wins
     double best = 0.0;
     for (int th = 1; th <= a.Ho && th * a.PW4 <= 128; ++th) {
-        const int xr = (th - 1) * stride + 3;
-        if (8 * xr * a.XP > 256 * WC_MAXX || xr * a.XP > 300) break;
+        const int xr = (th - 1) * stride + ks;
+        if (ks == 3 && (8 * xr * a.XP > 256 * 10 || xr * a.XP > 300)) break;
         const int nkb = (th * a.PW4 + 15) / 16, ty = (a.Ho + th - 1) / th;
         const double util = (double)a.Ho * a.Wo / ((double)ty * nkb * 16) * (1.0 - 0.2 / nkb);  // (fixed cost per tile: barriers, staging)
         if (util > best) {
@@ -2657,12 +2673,12 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
         }
     }
     if (a.TH == 0) return p;
-    a.XR = (a.TH - 1) * stride + 3;
+    a.XR = (a.TH - 1) * stride + ks;
     a.nkb = (a.TH * a.PW4 + 15) / 16;
     a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
     a.ntiles = N * a.tiles_y;
-    a.nW = Cout * Cin * 9;
-    const int gy = (Cout + 63) / 64, gz = Cin / 32;
+    a.nW = Cout * Cin * ks * ks;
+    const int gy = (Cout + 63) / 64, gz = Cin / (16 * NG);
     if (gy >= 65536 || gz >= 65536) return p;
     // slabs: one round of workgroups over the chip's 512 places (every slab costs a pass over dW), at least 2 tiles per
     // slab, at most 256 slabs
@@ -2670,7 +2686,8 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (a.ntiles + 1) / 2));
     a.nslab = (int)std::min<long long>(want, a.ntiles);
     p.grid = dim3((unsigned)a.nslab, (unsigned)gy, (unsigned)gz);
-    p.lds = std::max(((size_t)a.nkb * 16 * WC_CSA + (size_t)a.XR * a.XP * WC_CSX) * 4, (size_t)64 * WC_TP * 4);
+    const size_t ximg = ks == 1 ? (size_t)a.nkb * 16 : (size_t)a.XR * a.XP;
+    p.lds = std::max(((size_t)a.nkb * 16 * WC_CSA + ximg * CSX) * 4, (size_t)64 * (row + 4) * 4);
     p.ws_bytes = (size_t)a.nslab * a.nW * 4;
     p.use = true;
     return p;
@@ -2841,15 +2858,17 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
             AQ_REQUIRE(workspace && workspace_bytes >= cp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", cp.ws_bytes,
                        workspace_bytes);
             cp.a.x = x; cp.a.dy = dy; cp.a.part = static_cast<float *>(workspace);
-            if (stride == 1) {
-                auto kern = conv_wgrad_c16_kernel<1>;
-                if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds);
-                hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);
-            } else {
-                auto kern = conv_wgrad_c16_kernel<2>;
-                if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds);
-                hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);
-            }
+#define AQ_WC(SS, KK, GG)                                                                                                          \
+    {                                                                                                                              \
+        auto kern = conv_wgrad_c16_kernel<SS, KK, GG>;                                                                             \
+        if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds); \
+        hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);                                                            \
+    }
+            if (ks == 3 && stride == 1) AQ_WC(1, 3, 2)
+            else if (ks == 3) AQ_WC(2, 3, 2)
+            else if (stride == 1) AQ_WC(1, 1, 4)
+            else AQ_WC(2, 1, 4)
+#undef AQ_WC
             *nslab_out = cp.a.nslab;
             return check_launch("aq_conv_wgrad");
         }

@@ -40,6 +40,8 @@ SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (64, 64, 3, 2, 2, 12, 10, 2),      # many-channel weight-gradient kernel: stride 2 with padding 2
     (32, 48, 3, 1, 1, 7, 7, 5),        # ... whole 7 x 7 images per tile, rows padded to 8 pixels, 48 output channels
     (64, 80, 3, 2, 1, 17, 15, 3),      # ... stride 2 on odd sizes, a ragged group of output channels
+    (64, 64, 1, 1, 0, 9, 9, 2),        # ... 1x1 at stride 1
+    (128, 48, 1, 2, 0, 11, 11, 3),     # ... 1x1 at stride 2 on odd sizes
 ]
 
 
