@@ -559,11 +559,17 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
 constexpr int C3_CS = 20;
 constexpr int C3_MAXIT = 6;  // staging items (pixel, group of 4 channels) per thread: 4 * plane <= 256 * C3_MAXIT
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
+// PY, PX < 0: all nine taps.  PY, PX in {0, 1} (stride-2 input gradient by output parity class, MODE_DGRAD only): the class
+// (cy, cx) of dx[2a + cy][2b + cx] only receives the taps ty = PY, PY + 2, .. (PY = (cy + pad) & 1), likewise tx, read from
+// the UNDILATED dy at row a + (cy + pad - ty) / 2: a quarter of the matrix work of the zero-dilated form.  The tile is
+// TH x TW positions (a, b) of the class grid.
+template <int NT, int MODE, int PY, int PX>
+__device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy, const int cx)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr bool PAR = PY >= 0;
+    constexpr int NY = PY < 0 ? 3 : (PY == 0 ? 2 : 1), NX = PX < 0 ? 3 : (PX == 0 ? 2 : 1), NTAP = NY * NX;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jn = lane & 15, kq = lane >> 4;
@@ -577,12 +583,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
     const int bufsz = a.plane * C3_CS;
     const int chs = a.IH * a.IW;
     const float *img = a.in + (long long)n * a.KC * chs;
+    // PAR: input offset of tap i of a dimension is d(i) = (c + pad - t(i)) / 2 with t(i) = P + 2i; the image starts at the
+    // smallest of them (that of the last tap)
+    const int padF = 2 - a.padT;
+    const int dminy = PAR ? (cy + padF - (PY + 2 * (NY - 1))) / 2 : 0, dminx = PAR ? (cx + padF - (PX + 2 * (NX - 1))) / 2 : 0;
 
     // staging: item i = (group of 4 channels cg, plane element e), cg-major so that neighbouring lanes read neighbouring
     // pixels of one channel; goff = offset inside the chunk's 16 channel planes (-1: padding, -2: no item)
     int goff[C3_MAXIT], loff[C3_MAXIT];
     {
-        const int r0 = oy0 * a.rs - a.padT, c0 = ox0 * a.rs - a.padT;
+        const int r0 = PAR ? oy0 + dminy : oy0 * a.rs - a.padT, c0 = PAR ? ox0 + dminx : ox0 * a.rs - a.padT;
 #pragma unroll
         for (int it = 0; it < C3_MAXIT; ++it) {
             const int i = tid + 256 * it;
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
 
     // A: 36 floats per lane and chunk.  Forward: W[row][cbase + 4*kq ..+3][0..8] is one aligned run; element (t, tap)
     // sits at 9*t + tap.  Input gradient: row = input channel, W[cbase + 4*kq + t][row][0..8], four runs of 9, used
-    // with the tap flipped.
+    // with the tap flipped (or, by parity classes, with the forward tap itself).
     const int row = m0 + jn;
     const bool rok = row < a.M;
     auto load_a = [&](int cbase, float (&A)[36]) {
@@ -649,10 +659,24 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
         const int pr = 16 * t + jn;  // (a tile of TH x TW pixels may leave the last of the 16 * NT slots empty)
         const bool used = pr < a.TW * a.TH;
         const int py = used ? pr / a.TW : 0, px = used ? pr - py * a.TW : 0;
-        pb[t] = (py * a.rs * a.pitch + px * a.rs) * C3_CS + 4 * kq;
-        const int oy = oy0 + py, ox = ox0 + px;
+        const int rs = PAR ? 1 : a.rs;
+        pb[t] = (py * rs * a.pitch + px * rs) * C3_CS + 4 * kq;
+        int oy = oy0 + py, ox = ox0 + px;
+        if (PAR) {
+            oy = 2 * oy + cy;
+            ox = 2 * ox + cx;
+        }
         oyx[t] = (used && oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
     }
+    // LDS offset and A index of tap i (compile-time i)
+    auto tap_off = [&](int i) {
+        const int iy = i / NX, ix = i - NX * iy;
+        if (PAR) {
+            const int t_y = PY + 2 * iy, t_x = PX + 2 * ix;
+            return (((cy + padF - t_y) / 2 - dminy) * a.pitch + ((cx + padF - t_x) / 2 - dminx)) * C3_CS;
+        }
+        return (iy * a.pitch + ix) * C3_CS;
+    };
 
     floatx4 acc[NT];
 #pragma unroll
@@ -673,16 +697,20 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
         }
         const float *buf = smem + (c & 1) * bufsz;
         f4 b[NT], bn[NT];
+        {
+            const int toff = tap_off(0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt]);
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
+        }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) {
-                const int toff = (((tap + 1) / 3) * a.pitch + (tap + 1) % 3) * C3_CS;
+        for (int tap = 0; tap < NTAP; ++tap) {
+            if (tap + 1 < NTAP) {
+                const int toff = tap_off(tap + 1);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bn[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
             }
-            const int ta = MODE == MODE_DGRAD ? 8 - tap : tap;
+            // index of the tap's weight inside a lane's run of 9
+            const int ta = PAR ? (PY + 2 * (tap / NX)) * 3 + PX + 2 * (tap % NX) : (MODE == MODE_DGRAD ? 8 - tap : tap);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -710,6 +738,25 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
             }
         }
     }
+}
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
+{
+    conv3x3_c16_body<NT, MODE, -1, -1>(a, 0, 0);
+}
+
+// stride-2 input gradient: blockIdx.z = 2 * cy + cx, one body per tap parity
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_c16_par_kernel(const ConvArgs a)
+{
+    const int cy = (int)blockIdx.z >> 1, cx = (int)blockIdx.z & 1;
+    const int padF = 2 - a.padT;
+    const int py = (cy + padF) & 1, px = (cx + padF) & 1;
+    if (py == 0 && px == 0) conv3x3_c16_body<NT, MODE_DGRAD, 0, 0>(a, cy, cx);
+    else if (py == 0) conv3x3_c16_body<NT, MODE_DGRAD, 0, 1>(a, cy, cx);
+    else if (px == 0) conv3x3_c16_body<NT, MODE_DGRAD, 1, 0>(a, cy, cx);
+    else conv3x3_c16_body<NT, MODE_DGRAD, 1, 1>(a, cy, cx);
 }
 
 // sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), the same bits in each of them
@@ -2085,27 +2132,33 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
     *taken = false;
     if constexpr (MODE == MODE_FWD_CODES) return 0;
     else {
-    if (a.ks != 3 || a.KC % 16 != 0 || a.M < 48 || a.dil != 1 || a.bn_on || a.stat_part || a.bwd_part) return 0;
+    if (a.ks != 3 || a.KC % 16 != 0 || a.M < 48 || a.bn_on || a.stat_part || a.bwd_part) return 0;
+    const bool par = MODE == MODE_DGRAD && a.dil == 2;  // stride-2 input gradient: by output parity classes
+    if (a.dil != 1 && !par) return 0;
     if (MODE == MODE_FWD && (((uintptr_t)a.W & 15) != 0)) return 0;
     if ((long long)a.IH * a.IW * 16 >= (1LL << 31)) return 0;
     const int mgroups = (a.M + 63) / 64;
+    // grid the tiles are cut from: the output, or (par) one parity class of it, four of them per image
+    const int gw = par ? (a.OW + 1) / 2 : a.OW, gh = par ? (a.OH + 1) / 2 : a.OH, nclass = par ? 4 : 1;
+    const int rs = par ? 1 : a.rs, span = par ? 2 : 3;  // step between neighbouring pixels / extra rows and columns of the LDS image
     // tile = TH x TW output pixels in 16 * NT slots.  Candidates: full-width rows (no ragged last column) or 32 / 16 / 8
     // columns, NT = 2 .. 8; the choice maximises (share of slots that hold a pixel) x (share of the chip's 512
     // workgroup places that the last round of workgroups fills), with a slight preference for larger tiles.
     int NT = 0;
     double best = 0.0;
-    const int tws[4] = {a.OW <= 64 ? a.OW : 0, 32, 16, 8};
+    const int tws[4] = {gw <= 64 ? gw : 0, 32, 16, 8};
     for (int ti = 0; ti < 4; ++ti) {
         const int tw = tws[ti];
-        if (tw <= 0 || (ti > 0 && tw >= 2 * a.OW)) continue;
+        if (tw <= 0 || (ti > 0 && tw >= 2 * gw)) continue;
         for (int nt = 8; nt >= 2; --nt) {
-            int th = std::min(16 * nt / tw, a.OH);
+            if (par && nt != 8 && nt != 4 && nt != 2) continue;
+            int th = std::min(16 * nt / tw, gh);
             if (th < 1) continue;
-            const int plane = ((th - 1) * a.rs + 3) * ((tw - 1) * a.rs + 3);
+            const int plane = ((th - 1) * rs + span) * ((tw - 1) * rs + span);
             if (4 * plane > 256 * C3_MAXIT) continue;
-            const long long tiles = (long long)((a.OW + tw - 1) / tw) * ((a.OH + th - 1) / th);
-            const long long blocks = (long long)N * tiles * mgroups;
-            const double util = (double)a.OW * a.OH / ((double)tiles * 16 * nt);
+            const long long tiles = (long long)((gw + tw - 1) / tw) * ((gh + th - 1) / th);
+            const long long blocks = (long long)N * tiles * mgroups * nclass;
+            const double util = (double)gw * gh / ((double)tiles * 16 * nt);
             const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
             const double score = util * fill * (1.0 - 0.015 * (8 - nt));
             if (score > best) {
@@ -2117,20 +2170,28 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
         }
     }
     if (NT == 0) return 0;
-    a.tiles_x = (a.OW + a.TW - 1) / a.TW;
-    a.tiles_y = (a.OH + a.TH - 1) / a.TH;
-    a.pitch = (a.TW - 1) * a.rs + 3;
-    a.rows_in = (a.TH - 1) * a.rs + 3;
+    a.tiles_x = (gw + a.TW - 1) / a.TW;
+    a.tiles_y = (gh + a.TH - 1) / a.TH;
+    a.pitch = (a.TW - 1) * rs + span;
+    a.rows_in = (a.TH - 1) * rs + span;
     a.plane = a.rows_in * a.pitch;
-    a.par = 0;
+    a.par = par ? 1 : 0;
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     if (gx >= (1LL << 31) || mgroups >= 65536) return 0;
     const size_t lds = (size_t)2 * a.plane * C3_CS * 4;
-    dim3 grid((unsigned)gx, (unsigned)mgroups);
-    switch (NT) {
+    dim3 grid((unsigned)gx, (unsigned)mgroups, (unsigned)nclass);
+    if (par) {
+        if constexpr (MODE == MODE_DGRAD) {
+            if (NT == 8) hipLaunchKernelGGL((conv3x3_c16_par_kernel<8>), grid, dim3(256), lds, st, a);
+            else if (NT == 4) hipLaunchKernelGGL((conv3x3_c16_par_kernel<4>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3x3_c16_par_kernel<2>), grid, dim3(256), lds, st, a);
+        }
+    } else {
+        switch (NT) {
 #define AQ_C3(NN) case NN: hipLaunchKernelGGL((conv3x3_c16_kernel<NN, MODE>), grid, dim3(256), lds, st, a); break;
-        AQ_C3(2) AQ_C3(3) AQ_C3(4) AQ_C3(5) AQ_C3(6) AQ_C3(7) AQ_C3(8)
+            AQ_C3(2) AQ_C3(3) AQ_C3(4) AQ_C3(5) AQ_C3(6) AQ_C3(7) AQ_C3(8)
 #undef AQ_C3
+        }
     }
     *taken = true;
     return check_launch(who);
@@ -2650,6 +2711,14 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
 {
     using namespace aq;
     WgC16Plan p = {};
+    if (Cin <= 64 && Cout <= 64 && (long long)H * Wd <= 1024) {  // the reference's ResNet-20 layers keep their tuned variant of the small-channel kernel
+        WgradArgs t = {};
+        t.N = N; t.Cin = Cin; t.H = H; t.Wd = Wd; t.Cout = Cout; t.stride = stride; t.ks = ks; t.pad = pad;
+        int MGs, NGs;
+        dim3 g;
+        size_t l, w;
+        if (wgrad_plan(t, MGs, NGs, g, l, w) == 0 && wgrad_variant(t, MGs, NGs) != 0) return p;
+    }
     if (!(ks == 3 && Cin % 32 == 0) && !(ks == 1 && Cin % 64 == 0 && pad == 0)) return p;
     if (Cout % 16 != 0 || Cout < 48 || N < 1) return p;
     const int NG = ks == 3 ? 2 : 4, CSX = 16 * NG + 4, row = 16 * NG * ks * ks;

@@ -42,6 +42,8 @@ SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (64, 80, 3, 2, 1, 17, 15, 3),      # ... stride 2 on odd sizes, a ragged group of output channels
     (64, 64, 1, 1, 0, 9, 9, 2),        # ... 1x1 at stride 1
     (128, 48, 1, 2, 0, 11, 11, 3),     # ... 1x1 at stride 2 on odd sizes
+    (48, 64, 3, 2, 0, 13, 14, 2),      # stride-2 input gradient by parity classes in the many-channel kernel: no padding
+    (64, 96, 3, 2, 1, 30, 22, 2),      # ... padding 1, even sizes that are no multiples of the tile
 ]
 
 
