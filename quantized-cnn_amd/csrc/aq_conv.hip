@@ -559,17 +559,11 @@ __global__ __launch_bounds__(256) void conv_gemm_chunked_kernel(const ConvArgs a
 constexpr int C3_CS = 20;
 constexpr int C3_MAXIT = 6;  // staging items (pixel, group of 4 channels) per thread: 4 * plane <= 256 * C3_MAXIT
 
-// PY, PX < 0: all nine taps.  PY, PX in {0, 1} (stride-2 input gradient by output parity class, MODE_DGRAD only): the class
-// (cy, cx) of dx[2a + cy][2b + cx] only receives the taps ty = PY, PY + 2, .. (PY = (cy + pad) & 1), likewise tx, read from
-// the UNDILATED dy at row a + (cy + pad - ty) / 2: a quarter of the matrix work of the zero-dilated form.  The tile is
-// TH x TW positions (a, b) of the class grid.
-template <int NT, int MODE, int PY, int PX>
-__device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy, const int cx)
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr bool PAR = PY >= 0;
-    constexpr int NY = PY < 0 ? 3 : (PY == 0 ? 2 : 1), NX = PX < 0 ? 3 : (PX == 0 ? 2 : 1), NTAP = NY * NX;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jn = lane & 15, kq = lane >> 4;
@@ -583,16 +577,12 @@ __device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy
     const int bufsz = a.plane * C3_CS;
     const int chs = a.IH * a.IW;
     const float *img = a.in + (long long)n * a.KC * chs;
-    // PAR: input offset of tap i of a dimension is d(i) = (c + pad - t(i)) / 2 with t(i) = P + 2i; the image starts at the
-    // smallest of them (that of the last tap)
-    const int padF = 2 - a.padT;
-    const int dminy = PAR ? (cy + padF - (PY + 2 * (NY - 1))) / 2 : 0, dminx = PAR ? (cx + padF - (PX + 2 * (NX - 1))) / 2 : 0;
 
     // staging: item i = (group of 4 channels cg, plane element e), cg-major so that neighbouring lanes read neighbouring
     // pixels of one channel; goff = offset inside the chunk's 16 channel planes (-1: padding, -2: no item)
     int goff[C3_MAXIT], loff[C3_MAXIT];
     {
-        const int r0 = PAR ? oy0 + dminy : oy0 * a.rs - a.padT, c0 = PAR ? ox0 + dminx : ox0 * a.rs - a.padT;
+        const int r0 = oy0 * a.rs - a.padT, c0 = ox0 * a.rs - a.padT;
 #pragma unroll
         for (int it = 0; it < C3_MAXIT; ++it) {
             const int i = tid + 256 * it;
@@ -627,7 +617,7 @@ __device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy
 
     // A: 36 floats per lane and chunk.  Forward: W[row][cbase + 4*kq ..+3][0..8] is one aligned run; element (t, tap)
     // sits at 9*t + tap.  Input gradient: row = input channel, W[cbase + 4*kq + t][row][0..8], four runs of 9, used
-    // with the tap flipped (or, by parity classes, with the forward tap itself).
+    // with the tap flipped.
     const int row = m0 + jn;
     const bool rok = row < a.M;
     auto load_a = [&](int cbase, float (&A)[36]) {
@@ -659,24 +649,11 @@ __device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy
         const int pr = 16 * t + jn;  // (a tile of TH x TW pixels may leave the last of the 16 * NT slots empty)
         const bool used = pr < a.TW * a.TH;
         const int py = used ? pr / a.TW : 0, px = used ? pr - py * a.TW : 0;
-        const int rs = PAR ? 1 : a.rs;
-        pb[t] = (py * rs * a.pitch + px * rs) * C3_CS + 4 * kq;
-        int oy = oy0 + py, ox = ox0 + px;
-        if (PAR) {
-            oy = 2 * oy + cy;
-            ox = 2 * ox + cx;
-        }
+        pb[t] = (py * a.rs * a.pitch + px * a.rs) * C3_CS + 4 * kq;
+        const int oy = oy0 + py, ox = ox0 + px;
         oyx[t] = (used && oy < a.OH && ox < a.OW) ? ((oy << 16) | ox) : -1;
     }
-    // LDS offset and A index of tap i (compile-time i)
-    auto tap_off = [&](int i) {
-        const int iy = i / NX, ix = i - NX * iy;
-        if (PAR) {
-            const int t_y = PY + 2 * iy, t_x = PX + 2 * ix;
-            return (((cy + padF - t_y) / 2 - dminy) * a.pitch + ((cx + padF - t_x) / 2 - dminx)) * C3_CS;
-        }
-        return (iy * a.pitch + ix) * C3_CS;
-    };
+    auto tap_off = [&](int i) { return ((i / 3) * a.pitch + i % 3) * C3_CS; };  // LDS offset of tap i
 
     floatx4 acc[NT];
 #pragma unroll
@@ -703,14 +680,14 @@ __device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy
             for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
         }
 #pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            if (tap + 1 < NTAP) {
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
                 const int toff = tap_off(tap + 1);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bn[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
             }
             // index of the tap's weight inside a lane's run of 9
-            const int ta = PAR ? (PY + 2 * (tap / NX)) * 3 + PX + 2 * (tap % NX) : (MODE == MODE_DGRAD ? 8 - tap : tap);
+            const int ta = MODE == MODE_DGRAD ? 8 - tap : tap;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -740,23 +717,148 @@ __device__ __forceinline__ void conv3x3_c16_body(const ConvArgs &a, const int cy
     }
 }
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a)
+// Stride-2 input gradient, all four output parity classes from one workgroup: the tile is TH x TW positions (a, b) of the
+// class grid, the LDS image holds the undilated dy around them ((TH + 1) x (TW + 1) pixels), and every tap (ty, tx) of the
+// nine feeds the class (cy, cx) = ((ty + pad) & 1, (tx + pad) & 1) of dx[2a + cy][2b + cx], reading dy at row
+// a + (cy + pad - ty) / 2.  Nine taps per staged chunk as in the forward kernel (the one-class form above stages a chunk
+// for one to four taps), at the price of four accumulator sets: NT <= 4.  PP = pad & 1.
+template <int NT, int PP>
+__global__ __launch_bounds__(256) void conv3x3_c16_dgrad2_kernel(const ConvArgs a)
 {
-    conv3x3_c16_body<NT, MODE, -1, -1>(a, 0, 0);
-}
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jn = lane & 15, kq = lane >> 4;
 
-// stride-2 input gradient: blockIdx.z = 2 * cy + cx, one body per tap parity
-template <int NT>
-__global__ __launch_bounds__(256) void conv3x3_c16_par_kernel(const ConvArgs a)
-{
-    const int cy = (int)blockIdx.z >> 1, cx = (int)blockIdx.z & 1;
+    int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int m0 = blockIdx.y * 64 + wave * 16;
+    const int bufsz = a.plane * C3_CS;
+    const int chs = a.IH * a.IW;
+    const float *img = a.in + (long long)n * a.KC * chs;
     const int padF = 2 - a.padT;
-    const int py = (cy + padF) & 1, px = (cx + padF) & 1;
-    if (py == 0 && px == 0) conv3x3_c16_body<NT, MODE_DGRAD, 0, 0>(a, cy, cx);
-    else if (py == 0) conv3x3_c16_body<NT, MODE_DGRAD, 0, 1>(a, cy, cx);
-    else if (px == 0) conv3x3_c16_body<NT, MODE_DGRAD, 1, 0>(a, cy, cx);
-    else conv3x3_c16_body<NT, MODE_DGRAD, 1, 1>(a, cy, cx);
+    // input offset of tap t (either dimension): d(t) = (c + pad - t) / 2 with c = (t + pad) & 1; smallest over the taps
+    auto dtap = [&](int t) { return (((t + PP) & 1) + padF - t) / 2; };
+    const int dmin = min(dtap(0), min(dtap(1), dtap(2)));
+
+    int goff[C3_MAXIT], loff[C3_MAXIT];
+    {
+        const int r0 = oy0 + dmin, c0 = ox0 + dmin;
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it) {
+            const int i = tid + 256 * it;
+            goff[it] = -2;
+            loff[it] = 0;
+            if (i < 4 * a.plane) {
+                const int cg = i / a.plane, e = i - cg * a.plane;
+                const int r = e / a.pitch, cc = e - r * a.pitch;
+                const int gy = r0 + r, gx = c0 + cc;
+                const bool ok = gy >= 0 && gx >= 0 && gy < a.IH && gx < a.IW;
+                goff[it] = ok ? 4 * cg * chs + gy * a.IW + gx : -1;
+                loff[it] = e * C3_CS + 4 * cg;
+            }
+        }
+    }
+    auto stage_load = [&](int cbase, f4 (&xr)[C3_MAXIT]) {
+        const float *src = img + (long long)cbase * chs;
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it) {
+            xr[it] = f4{0.f, 0.f, 0.f, 0.f};
+            if (goff[it] >= 0) {
+                const float *s0 = src + goff[it];
+                xr[it] = f4{s0[0], s0[chs], s0[2 * chs], s0[3 * chs]};
+            }
+        }
+    };
+    auto stage_store = [&](float *buf, const f4 (&xr)[C3_MAXIT]) {
+#pragma unroll
+        for (int it = 0; it < C3_MAXIT; ++it)
+            if (goff[it] != -2) *reinterpret_cast<f4 *>(buf + loff[it]) = xr[it];
+    };
+    const int row = m0 + jn;  // input channel
+    const bool rok = row < a.M;
+    auto load_a = [&](int cbase, float (&A)[36]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float *w = a.W + ((long long)(cbase + 4 * kq + t) * a.Cin + (rok ? row : 0)) * 9;
+            __builtin_memcpy(&A[9 * t], w, 16);
+            __builtin_memcpy(&A[9 * t + 4], w + 4, 16);
+            A[9 * t + 8] = w[8];
+        }
+        if (!rok) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) A[i] = 0.0f;
+        }
+    };
+
+    int pb[NT], pyx[NT];  // pyx = (py << 16) | px of the slot inside the tile, -1: empty slot
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int pr = 16 * t + jn;
+        const bool used = pr < a.TW * a.TH;
+        const int py = used ? pr / a.TW : 0, px = used ? pr - py * a.TW : 0;
+        pb[t] = (py * a.pitch + px) * C3_CS + 4 * kq;
+        pyx[t] = used ? ((py << 16) | px) : -1;
+    }
+    floatx4 acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[c][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = a.KC >> 4;
+    float A[36], An[36];
+    f4 xr[C3_MAXIT];
+    stage_load(0, xr);
+    load_a(0, A);
+    stage_store(smem, xr);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) {
+            stage_load(16 * (c + 1), xr);
+            load_a(16 * (c + 1), An);
+        }
+        const float *buf = smem + (c & 1) * bufsz;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t_y = tap / 3, t_x = tap % 3;
+            const int cls = 2 * ((t_y + PP) & 1) + ((t_x + PP) & 1);
+            const int toff = ((dtap(t_y) - dmin) * a.pitch + (dtap(t_x) - dmin)) * C3_CS;
+            f4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f4 *>(buf + pb[nt] + toff);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[cls][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[9 * t + tap], b[nt][t], acc[cls][nt], 0, 0, 0);
+        }
+        if (more) stage_store(smem + ((c + 1) & 1) * bufsz, xr);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A[i] = An[i];
+    }
+
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (pyx[nt] < 0) continue;
+            const int oy = 2 * (oy0 + (pyx[nt] >> 16)) + (cls >> 1), ox = 2 * (ox0 + (pyx[nt] & 0xffff)) + (cls & 1);
+            if (oy >= a.OH || ox >= a.OW) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = m0 + 4 * kq + r;
+                if (ch < a.M) {
+                    const long long o = (((long long)n * a.M + ch) * a.OH + oy) * a.OW + ox;
+                    a.out[o] = a.res ? acc[cls][nt][r] + a.res[o] : acc[cls][nt][r];
+                }
+            }
+        }
 }
 
 // sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), the same bits in each of them
@@ -2139,7 +2241,7 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
     if ((long long)a.IH * a.IW * 16 >= (1LL << 31)) return 0;
     const int mgroups = (a.M + 63) / 64;
     // grid the tiles are cut from: the output, or (par) one parity class of it, four of them per image
-    const int gw = par ? (a.OW + 1) / 2 : a.OW, gh = par ? (a.OH + 1) / 2 : a.OH, nclass = par ? 4 : 1;
+    const int gw = par ? (a.OW + 1) / 2 : a.OW, gh = par ? (a.OH + 1) / 2 : a.OH;
     const int rs = par ? 1 : a.rs, span = par ? 2 : 3;  // step between neighbouring pixels / extra rows and columns of the LDS image
     // tile = TH x TW output pixels in 16 * NT slots.  Candidates: full-width rows (no ragged last column) or 32 / 16 / 8
     // columns, NT = 2 .. 8; the choice maximises (share of slots that hold a pixel) x (share of the chip's 512
@@ -2151,13 +2253,13 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
         const int tw = tws[ti];
         if (tw <= 0 || (ti > 0 && tw >= 2 * gw)) continue;
         for (int nt = 8; nt >= 2; --nt) {
-            if (par && nt != 8 && nt != 4 && nt != 2) continue;
+            if (par && nt != 4 && nt != 2) continue;  // (four accumulator sets per slot)
             int th = std::min(16 * nt / tw, gh);
             if (th < 1) continue;
             const int plane = ((th - 1) * rs + span) * ((tw - 1) * rs + span);
             if (4 * plane > 256 * C3_MAXIT) continue;
             const long long tiles = (long long)((gw + tw - 1) / tw) * ((gh + th - 1) / th);
-            const long long blocks = (long long)N * tiles * mgroups * nclass;
+            const long long blocks = (long long)N * tiles * mgroups;
             const double util = (double)gw * gh / ((double)tiles * 16 * nt);
             const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
             const double score = util * fill * (1.0 - 0.015 * (8 - nt));
@@ -2179,12 +2281,14 @@ static int launch_c3(ConvArgs a, int N, hipStream_t st, const char *who, bool *t
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
     if (gx >= (1LL << 31) || mgroups >= 65536) return 0;
     const size_t lds = (size_t)2 * a.plane * C3_CS * 4;
-    dim3 grid((unsigned)gx, (unsigned)mgroups, (unsigned)nclass);
+    dim3 grid((unsigned)gx, (unsigned)mgroups);
     if (par) {
         if constexpr (MODE == MODE_DGRAD) {
-            if (NT == 8) hipLaunchKernelGGL((conv3x3_c16_par_kernel<8>), grid, dim3(256), lds, st, a);
-            else if (NT == 4) hipLaunchKernelGGL((conv3x3_c16_par_kernel<4>), grid, dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((conv3x3_c16_par_kernel<2>), grid, dim3(256), lds, st, a);
+            const int pp = (2 - a.padT) & 1;
+            if (NT == 4 && pp) hipLaunchKernelGGL((conv3x3_c16_dgrad2_kernel<4, 1>), grid, dim3(256), lds, st, a);
+            else if (NT == 4) hipLaunchKernelGGL((conv3x3_c16_dgrad2_kernel<4, 0>), grid, dim3(256), lds, st, a);
+            else if (pp) hipLaunchKernelGGL((conv3x3_c16_dgrad2_kernel<2, 1>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv3x3_c16_dgrad2_kernel<2, 0>), grid, dim3(256), lds, st, a);
         }
     } else {
         switch (NT) {
