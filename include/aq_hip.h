@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 9
+#define AQ_ABI_VERSION 10
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -178,6 +178,15 @@ typedef struct aq_wgrad_job {
 int aq_conv_wgrad_partial(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout,
                           int ksize, int stride, int pad, void *workspace, size_t workspace_bytes,
                           int *nslab, void *stream);
+/* aq_conv_wgrad_partial for nlayers layers of ONE shape in one launch (groups of 8): the weight gradients of a backward
+ * pass (autograd of adp_qtz_fan.py:574-601, one per MyConv2d) depend only on their own (x, dy), so a training step can
+ * collect the layers of a residual stage and run them together at the end of the pass.  x[l], dy[l], workspace[l]:
+ * host arrays of device pointers; every workspace has workspace_bytes (aq_conv_wgrad_workspace_bytes); *nslab: slabs
+ * per layer (the same for all; fewer than a single-layer call makes when the layers together fill the chip, so the
+ * sums agree with nlayers calls of aq_conv_wgrad_partial up to fp32 summation order, and are reproducible). */
+int aq_conv_wgrad_partial_group(const float *const *x, const float *const *dy, void *const *workspace,
+                                int nlayers, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride,
+                                int pad, size_t workspace_bytes, int *nslab, void *stream);
 int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream);
 
 /* MyLinear (adp_qtz_fan.py:646-647): y[N,Out] = x[N,In] @ W[In,Out] + bias[Out]; and its gradients

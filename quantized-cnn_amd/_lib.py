@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -21,7 +21,7 @@ EXPORTS = (
     "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
-    "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
+    "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_partial_group", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
     "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_ce_loss",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
@@ -92,6 +92,7 @@ def lib():
         L.aq_conv_dgrad_add.restype = i
         L.aq_conv_wgrad.argtypes = [vp, vp, vp] + conv_dims + [vp, sz, vp]
         L.aq_conv_wgrad_partial.argtypes = [vp, vp] + conv_dims + [vp, sz, C.POINTER(C.c_int), vp]
+        L.aq_conv_wgrad_partial_group.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int] + conv_dims + [sz, C.POINTER(C.c_int), vp]
         L.aq_conv_wgrad_reduce.argtypes = [C.POINTER(AqWgradJob), i, vp]
         L.aq_conv_wgrad_workspace_bytes.argtypes = conv_dims
         L.aq_conv_wgrad_workspace_bytes.restype = sz

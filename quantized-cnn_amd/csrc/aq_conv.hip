@@ -1687,6 +1687,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a)
     conv_wgrad_body<MG, NG, CH4, J>(a, BlockCoord{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x});
 }
 
+// The same for up to WGRAD_GROUP_MAX layers of one shape in one launch (the weight gradients of a backward pass depend on
+// nothing but their own (x, dy), so they can all wait for its end): layer l owns the blocks [l * gx, (l + 1) * gx) of the
+// grid's x axis.  One launch of a single layer fills a fraction of the chip and pays the launch floor alone.
+constexpr int WGRAD_GROUP_MAX = 8;
+struct WgradGroup {
+    const float *x[WGRAD_GROUP_MAX], *dy[WGRAD_GROUP_MAX];
+    float *part[WGRAD_GROUP_MAX];
+    int n, gx;
+};
+template <int MG, int NG, int CH4, int J>
+__global__ __launch_bounds__(512) void conv_wgrad_group_kernel(const WgradArgs a, const WgradGroup g)
+{
+    const int l = (int)blockIdx.x / g.gx;
+    WgradArgs b = a;
+    b.x = g.x[l];
+    b.dy = g.dy[l];
+    b.part = g.part[l];
+    conv_wgrad_body<MG, NG, CH4, J>(b, BlockCoord{(int)blockIdx.x - l * g.gx, (int)blockIdx.y, (int)blockIdx.z, g.gx});
+}
+
 // Weight-gradient slabs for layers with many channels: a workgroup of four wavefronts owns 64 output channels x
 // 16*NG (ci, tap) columns (for 3x3 kernels: 16 input channels exactly), wavefront w the 16 channels 16w..16w+15 with all
 // NG column tiles in its accumulators, and walks over its share of the pixel chunks (TH x TW pixels of one image): the
@@ -1939,23 +1959,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradJo
 // tap shift.  Rows of the dy tile are padded to a multiple of 4 pixels (zeros), so the 4 pixels of a lane's k-group
 // stay in one row and the x image is addressed as base + tap + t * S pixels.  The next tile is fetched into registers
 // while the matrix work of the current one runs.
-constexpr int WC_CSA = 68;
-constexpr int WC_MAXA = 8;  // dy staging items per thread: 16 * slots <= 256 * WC_MAXA
 struct WgC16Args {
-    const float *x, *dy;
-    float *part;
     int N, Cin, H, Wd, Cout, Ho, Wo, pad;
     int TH, PW4, tiles_y, ntiles, nslab;
     int XR, XP, nkb, nW;
 };
 
-// S = stride, KS = 3 | 1 (kernel size), NG = groups of 16 input channels per workgroup (KS = 3: 2, KS = 1: 4).
+// S = stride, KS = 3 | 1 (kernel size), NG = groups of 16 input channels per workgroup (KS = 3: 1 or 2, KS = 1: 4).
 // KS = 1 (the projections of dimension-changing blocks): no taps, so x is staged like dy, one pixel per slot (only the
 // pixels the stride keeps), and the workgroup takes 64 input channels instead of 32.
-template <int S, int KS, int NG>
-__global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
+// CW = groups of 16 output channels per workgroup (4, 2 or 1 for 64+, 32, 16 output channels): the four wavefronts are
+// CW channel groups x 4 / CW shares of the k-blocks (wavefront w: group w % CW, k-blocks w / CW, w / CW + 4 / CW, ..);
+// the shares are summed in ascending order on the way out, so a layer with 16 output channels still uses all four
+// wavefronts' matrix pipes.
+template <int S, int KS, int NG, int CW>
+__global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a, const WgradGroup grp)
 {
     constexpr int T2 = KS * KS, CSX = 16 * NG + 4, CGX = 4 * NG, ROW = 16 * NG * T2, TP = ROW + 4;
+    constexpr int PW = 4 / CW, WC_CSA = 16 * CW + 4, WC_MAXA = 2 * CW;  // dy staging items per thread: 4 * CW * slots <= 256 * WC_MAXA
     constexpr int MAXX = KS == 1 ? 8 : 10;  // x staging items per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1965,7 +1986,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jn = lane & 15, kq = lane >> 4;
-    const int slab = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 16 * NG;
+    // layer l of the launch owns the blocks [l * nslab, (l + 1) * nslab) of the grid's x axis
+    const int layer = (int)blockIdx.x / a.nslab;
+    const int slab = (int)blockIdx.x - layer * a.nslab, co0 = blockIdx.y * 16 * CW, ci0 = blockIdx.z * 16 * NG;
+    const float *__restrict__ gx = grp.x[layer];
+    const float *__restrict__ gdy = grp.dy[layer];
+    const int cw = wave % CW, pw = wave / CW;
     const int HoWo = a.Ho * a.Wo, HW = a.H * a.Wd, npx = KS == 1 ? nslots : a.XR * a.XP;
 
     // staging items.  dy: (slot p, group of 4 channels), p-major inside a group; x: (image pixel or slot, group of 4 channels).
@@ -1977,7 +2003,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         const int i = tid + 256 * it;
         relA[it] = -1;
         locA[it] = -1;
-        if (i < 16 * nslots) {
+        if (i < 4 * CW * nslots) {
             const int cg = i / nslots, p = i - cg * nslots;
             const int py = p / a.PW4, px = p - py * a.PW4;
             const bool ok = px < a.Wo && py < a.TH && co0 + 4 * cg < a.Cout;
@@ -2009,7 +2035,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
     auto stage_load = [&](int tile, f4 (&ra)[WC_MAXA], f4 (&rx)[MAXX]) {
         const int n = tile / a.tiles_y, ty = tile - n * a.tiles_y;
         const int rows_left = a.Ho - ty * a.TH;
-        const float *da = a.dy + ((long long)n * a.Cout + co0) * HoWo + (long long)ty * a.TH * a.Wo;
+        const float *da = gdy + ((long long)n * a.Cout + co0) * HoWo + (long long)ty * a.TH * a.Wo;
 #pragma unroll
         for (int it = 0; it < WC_MAXA; ++it) {
             ra[it] = f4{0.f, 0.f, 0.f, 0.f};
@@ -2020,7 +2046,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
         }
         // KS = 3: image row of the x image's first row (may lie above the image); KS = 1: the tile's first kept row
         const int gy0 = ty * a.TH * S - (KS == 1 ? 0 : a.pad);
-        const float *dx = a.x + ((long long)n * a.Cin + ci0) * HW + (long long)gy0 * a.Wd;
+        const float *dx = gx + ((long long)n * a.Cin + ci0) * HW + (long long)gy0 * a.Wd;
 #pragma unroll
         for (int it = 0; it < MAXX; ++it) {
             rx[it] = f4{0.f, 0.f, 0.f, 0.f};
@@ -2058,9 +2084,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
     for (int tile = t0; tile < t1; ++tile) {
         const bool more = tile + 1 < t1;
         if (more) stage_load(tile + 1, ra, rx);
-        for (int kb = 0; kb < a.nkb; ++kb) {
+        for (int kb = pw; kb < a.nkb; kb += PW) {
             const int p = 16 * kb + 4 * kq;
-            const float *ap = dyS + p * WC_CSA + wave * 16 + jn;
+            const float *ap = dyS + p * WC_CSA + cw * 16 + jn;
             const float *bp;
             if (KS == 1) {
                 bp = xS + p * CSX + jn;
@@ -2088,8 +2114,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
     }
 
     // D[row = 4*kq + r -> co][col = jn -> ci]: through LDS, so that the slab is written as whole rows (output channel
-    // co: the workgroup's input channels x taps are contiguous in dW) with 16-byte stores
-    float *tileS = smem;  // [64][TP]
+    // co: the workgroup's input channels x taps are contiguous in dW) with 16-byte stores, the k-block shares of a
+    // channel group (wavefronts cw, cw + CW, ..) summed in that order
+    float *tileS = smem;  // [64][TP], rows 16 * wave ..
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -2097,11 +2124,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) tileS[(wave * 16 + 4 * kq + r) * TP + (16 * g + jn) * T2 + tap] = acc[g][tap][r];
     __syncthreads();
-    float *out = a.part + (long long)slab * a.nW + (long long)ci0 * T2;
-    for (int i = tid; i < 64 * (ROW / 4); i += 256) {
-        const int r = i / (ROW / 4), c = i - (ROW / 4) * r;
-        if (co0 + r < a.Cout)
-            *reinterpret_cast<f4 *>(out + (long long)(co0 + r) * a.Cin * T2 + 4 * c) = *reinterpret_cast<const f4 *>(tileS + r * TP + 4 * c);
+    float *out = grp.part[layer] + (long long)slab * a.nW + (long long)ci0 * T2;
+    for (int i = tid; i < 16 * CW * (ROW / 4); i += 256) {
+        const int r = i / (ROW / 4), c = i - (ROW / 4) * r;  // r = 16 * (channel group) + row
+        if (co0 + r < a.Cout) {
+            f4 v = *reinterpret_cast<const f4 *>(tileS + r * TP + 4 * c);
+#pragma unroll
+            for (int q = 1; q < PW; ++q) v += *reinterpret_cast<const f4 *>(tileS + (q * CW * 16 + r) * TP + 4 * c);
+            *reinterpret_cast<f4 *>(out + (long long)(co0 + r) * a.Cin * T2 + 4 * c) = v;
+        }
     }
 }
 
@@ -2804,28 +2835,25 @@ static WgradBigPlan wgrad_big_plan(aq::WgradArgs &a)
     return p;
 }
 
-// Plan of conv_wgrad_c16_kernel (3x3, input channels a multiple of 32, output channels a multiple of 16 and >= 48).
+// Plan of conv_wgrad_c16_kernel: 3x3 with input channels a multiple of 16, or 1x1 / padding 0 with input channels a
+// multiple of 64; output channels a multiple of 16.  nlayers: layers of this shape that share the launch (the slab
+// count is chosen so that all of them together make about one round of workgroups over the chip).
 struct WgC16Plan {
     bool use;
+    int NG, CW;
     aq::WgC16Args a;
     dim3 grid;
     size_t lds, ws_bytes;
 };
-static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad)
+static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad, int nlayers = 1)
 {
     using namespace aq;
     WgC16Plan p = {};
-    if (Cin <= 64 && Cout <= 64 && (long long)H * Wd <= 1024) {  // the reference's ResNet-20 layers keep their tuned variant of the small-channel kernel
-        WgradArgs t = {};
-        t.N = N; t.Cin = Cin; t.H = H; t.Wd = Wd; t.Cout = Cout; t.stride = stride; t.ks = ks; t.pad = pad;
-        int MGs, NGs;
-        dim3 g;
-        size_t l, w;
-        if (wgrad_plan(t, MGs, NGs, g, l, w) == 0 && wgrad_variant(t, MGs, NGs) != 0) return p;
-    }
-    if (!(ks == 3 && Cin % 32 == 0) && !(ks == 1 && Cin % 64 == 0 && pad == 0)) return p;
-    if (Cout % 16 != 0 || Cout < 48 || N < 1) return p;
-    const int NG = ks == 3 ? 2 : 4, CSX = 16 * NG + 4, row = 16 * NG * ks * ks;
+    if (!(ks == 3 && Cin % 16 == 0) && !(ks == 1 && Cin % 64 == 0 && pad == 0)) return p;
+    if (Cout % 16 != 0 || N < 1) return p;
+    const int NG = ks == 3 ? (Cin % 32 == 0 ? 2 : 1) : 4, CW = Cout >= 48 ? 4 : (Cout >= 32 ? 2 : 1);
+    const int CSX = 16 * NG + 4, CSA = 16 * CW + 4, row = 16 * NG * ks * ks;
+    p.NG = NG; p.CW = CW;
     WgC16Args &a = p.a;
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.pad = pad;
     a.Ho = conv_out(H, ks, stride, pad);
@@ -2837,7 +2865,7 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     double best = 0.0;
     for (int th = 1; th <= a.Ho && th * a.PW4 <= 128; ++th) {
         const int xr = (th - 1) * stride + ks;
-        if (ks == 3 && (8 * xr * a.XP > 256 * 10 || xr * a.XP > 300)) break;
+        if (ks == 3 && (4 * NG * xr * a.XP > 256 * 10 || xr * a.XP * CSX > 300 * 36)) break;
         const int nkb = (th * a.PW4 + 15) / 16, ty = (a.Ho + th - 1) / th;
         const double util = (double)a.Ho * a.Wo / ((double)ty * nkb * 16) * (1.0 - 0.2 / nkb);  // (fixed cost per tile: barriers, staging)
         if (util > best) {
@@ -2851,19 +2879,47 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
     a.ntiles = N * a.tiles_y;
     a.nW = Cout * Cin * ks * ks;
-    const int gy = (Cout + 63) / 64, gz = Cin / (16 * NG);
+    const int gy = (Cout + 16 * CW - 1) / (16 * CW), gz = Cin / (16 * NG);
     if (gy >= 65536 || gz >= 65536) return p;
-    // slabs: one round of workgroups over the chip's 512 places (every slab costs a pass over dW), at least 2 tiles per
-    // slab, at most 256 slabs
-    long long want = (512 + (long long)gy * gz - 1) / ((long long)gy * gz);
+    // slabs: one round of workgroups over the chip's 512 places for all layers of the launch together (every slab costs
+    // a pass over dW and a prologue), at least 2 tiles per slab, at most 256 slabs
+    const long long per = (long long)gy * gz * std::max(1, nlayers);
+    long long want = (512 + per - 1) / per;
     want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (a.ntiles + 1) / 2));
     a.nslab = (int)std::min<long long>(want, a.ntiles);
     p.grid = dim3((unsigned)a.nslab, (unsigned)gy, (unsigned)gz);
     const size_t ximg = ks == 1 ? (size_t)a.nkb * 16 : (size_t)a.XR * a.XP;
-    p.lds = std::max(((size_t)a.nkb * 16 * WC_CSA + ximg * CSX) * 4, (size_t)64 * (row + 4) * 4);
+    p.lds = std::max(((size_t)a.nkb * 16 * CSA + ximg * CSX) * 4, (size_t)64 * (row + 4) * 4);
     p.ws_bytes = (size_t)a.nslab * a.nW * 4;
     p.use = true;
     return p;
+}
+
+// launch of a planned conv_wgrad_c16_kernel
+static void wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st)
+{
+    using namespace aq;
+    dim3 grid = cp.grid;
+    grid.x *= (unsigned)g.n;
+#define AQ_WC(SS, KK, GG, CC)                                                                                                      \
+    {                                                                                                                              \
+        auto kern = conv_wgrad_c16_kernel<SS, KK, GG, CC>;                                                                         \
+        if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), cp.lds, st, cp.a, g);                                                            \
+    }
+#define AQ_WCC(SS, KK, GG)                        \
+    if (cp.CW == 4) AQ_WC(SS, KK, GG, 4)          \
+    else if (cp.CW == 2) AQ_WC(SS, KK, GG, 2)     \
+    else AQ_WC(SS, KK, GG, 1)
+    if (ks == 1) {
+        if (stride == 1) { AQ_WCC(1, 1, 4) } else { AQ_WCC(2, 1, 4) }
+    } else if (cp.NG == 2) {
+        if (stride == 1) { AQ_WCC(1, 3, 2) } else { AQ_WCC(2, 3, 2) }
+    } else {
+        if (stride == 1) { AQ_WCC(1, 3, 1) } else { AQ_WCC(2, 3, 1) }
+    }
+#undef AQ_WCC
+#undef AQ_WC
 }
 
 size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad)
@@ -2871,18 +2927,21 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
     if (aq::check_conv("aq_conv_wgrad_workspace_bytes", N, Cin, H, Wd, Cout, ksize, stride, pad) || N == 0) return 0;
     aq::WgradArgs a = {};
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ksize; a.pad = pad;
+    // the largest over the kernels that may take the shape (the variant that normalises x while staging it runs on the
+    // small-channel kernel whatever the plain weight gradient runs on)
+    size_t need = 0;
     {
         const WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ksize, stride, pad);
-        if (cp.use) return cp.ws_bytes;
+        if (cp.use) need = std::max(need, cp.ws_bytes);
         aq::WgradArgs b = a;
         const WgradBigPlan bp = wgrad_big_plan(b);
-        if (bp.use) return bp.ws_bytes;
+        if (bp.use) need = std::max(need, bp.ws_bytes);
     }
     int MG, NG;
     dim3 grid;
     size_t lds, ws;
-    if (wgrad_plan(a, MG, NG, grid, lds, ws)) return 0;
-    return ws;
+    if (wgrad_plan(a, MG, NG, grid, lds, ws) == 0) need = std::max(need, ws);
+    return need;
 }
 
 // register-staged loader variant (0: generic) for a planned launch: the tile must span the output width
@@ -2907,7 +2966,8 @@ struct BnOperand {  // statistics of the batch normalisation applied to x while 
 
 // slab kernel of aq_conv_wgrad; *nslab_out = number of slabs written to workspace ([nslab][Cout*Cin*9])
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn = nullptr, int ks = 3, int pad = 1);
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn = nullptr, int ks = 3, int pad = 1,
+                       const aq::WgradGroup *grp = nullptr);
 
 int aq_conv_wgrad(const float *x, const float *dy, float *dW, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad,
                   void *workspace, size_t workspace_bytes, void *stream)
@@ -2934,6 +2994,33 @@ int aq_conv_wgrad_partial(const float *x, const float *dy, int N, int Cin, int H
     *nslab = 0;
     if (N == 0) return 0;
     return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab, nullptr, ksize, pad);
+}
+
+int aq_conv_wgrad_partial_group(const float *const *x, const float *const *dy, void *const *workspace, int nlayers, int N, int Cin, int H, int Wd,
+                                int Cout, int ksize, int stride, int pad, size_t workspace_bytes, int *nslab, void *stream)
+{
+    using namespace aq;
+    if (int rc = check_conv("aq_conv_wgrad_partial_group", N, Cin, H, Wd, Cout, ksize, stride, pad)) return rc;
+    AQ_REQUIRE(nslab, -EFAULT, "aq_conv_wgrad_partial_group: NULL nslab");
+    *nslab = 0;
+    AQ_REQUIRE(nlayers >= 0 && (nlayers == 0 || (x && dy && workspace)), -EINVAL, "aq_conv_wgrad_partial_group: bad layer list");
+    if (N == 0 || nlayers == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < nlayers; base += WGRAD_GROUP_MAX) {
+        WgradGroup g = {};
+        g.n = std::min(WGRAD_GROUP_MAX, nlayers - base);
+        for (int l = 0; l < g.n; ++l) {
+            g.x[l] = x[base + l]; g.dy[l] = dy[base + l]; g.part[l] = static_cast<float *>(workspace[base + l]);
+        }
+        int rc = wgrad_slabs(nullptr, nullptr, N, Cin, H, Wd, Cout, stride, nullptr, workspace_bytes, st, nslab, nullptr, ksize, pad, &g);
+        if (rc == -ENOTSUP) {  // a shape of the many-channel kernels: one launch per layer
+            for (int l = 0; l < g.n; ++l)
+                if (int r2 = wgrad_slabs(g.x[l], g.dy[l], N, Cin, H, Wd, Cout, stride, g.part[l], workspace_bytes, st, nslab, nullptr, ksize, pad)) return r2;
+            rc = 0;
+        }
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int aq_conv_wgrad_reduce(const aq_wgrad_job *jobs, int njobs, void *stream)
@@ -3016,37 +3103,40 @@ int aq_bnconv_wgrad_partial(const float *x, const float *gamma, const float *bet
     return wgrad_slabs(x, dy, N, Cin, H, Wd, Cout, stride, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nslab, &bn);
 }
 
+// grp: several layers of this shape at once (x, dy, workspace then come from it, each workspace of workspace_bytes);
+// shapes that run on the many-channel kernels return -ENOTSUP for a group (the caller launches them one by one)
 static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, int Wd, int Cout, int stride, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn, int ks, int pad)
+                       size_t workspace_bytes, hipStream_t st, int *nslab_out, const BnOperand *bn, int ks, int pad, const aq::WgradGroup *grp)
 {
     using namespace aq;
+    if (grp) {
+        x = grp->x[0]; dy = grp->dy[0]; workspace = grp->part[0];
+    }
     AQ_REQUIRE(x && dy, -EFAULT, "aq_conv_wgrad: NULL pointer");
     WgradArgs a = {};
     a.x = x; a.dy = dy; a.part = static_cast<float *>(workspace);
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
     if (!bn) {
-        WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad);
+        WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad, grp ? grp->n : 1);
         if (cp.use) {
             AQ_REQUIRE(workspace && workspace_bytes >= cp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", cp.ws_bytes,
                        workspace_bytes);
-            cp.a.x = x; cp.a.dy = dy; cp.a.part = static_cast<float *>(workspace);
-#define AQ_WC(SS, KK, GG)                                                                                                          \
-    {                                                                                                                              \
-        auto kern = conv_wgrad_c16_kernel<SS, KK, GG>;                                                                             \
-        if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds); \
-        hipLaunchKernelGGL(kern, cp.grid, dim3(256), cp.lds, st, cp.a);                                                            \
-    }
-            if (ks == 3 && stride == 1) AQ_WC(1, 3, 2)
-            else if (ks == 3) AQ_WC(2, 3, 2)
-            else if (stride == 1) AQ_WC(1, 1, 4)
-            else AQ_WC(2, 1, 4)
-#undef AQ_WC
+            WgradGroup g1 = {};
+            if (grp) {
+                g1 = *grp;
+            } else {
+                g1.n = 1; g1.x[0] = x; g1.dy[0] = dy; g1.part[0] = static_cast<float *>(workspace);
+            }
+            for (int l = 0; l < g1.n; ++l) AQ_REQUIRE(g1.x[l] && g1.dy[l] && g1.part[l], -EFAULT, "aq_conv_wgrad: NULL pointer (layer %d)", l);
+            AQ_REQUIRE((long long)cp.grid.x * g1.n < (1LL << 31), -E2BIG, "aq_conv_wgrad: grid too large");
+            wgrad_c16_launch(cp, g1, ks, stride, st);
             *nslab_out = cp.a.nslab;
             return check_launch("aq_conv_wgrad");
         }
         WgradArgs b = a;
         const WgradBigPlan bp = wgrad_big_plan(b);
+        if (bp.use && grp) return -ENOTSUP;
         if (bp.use) {
             AQ_REQUIRE(workspace && workspace_bytes >= bp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", bp.ws_bytes,
                        workspace_bytes);
@@ -3062,18 +3152,26 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     AQ_REQUIRE(workspace && workspace_bytes >= ws, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", ws, workspace_bytes);
     const int variant = wgrad_variant(a, MG, NG);
     AQ_REQUIRE(variant != 0 || !a.bn_mean, -ENOTSUP, "aq_conv_wgrad: no kernel with fused input normalisation for this shape");
+    WgradGroup gg = {};
+    dim3 ggrid = grid;
+    if (grp) {
+        for (int l = 0; l < grp->n; ++l) AQ_REQUIRE(grp->x[l] && grp->dy[l] && grp->part[l], -EFAULT, "aq_conv_wgrad_partial_group: NULL pointer (layer %d)", l);
+        AQ_REQUIRE((long long)grid.x * grp->n < (1LL << 31), -E2BIG, "aq_conv_wgrad_partial_group: grid too large");
+        gg = *grp;
+        gg.gx = (int)grid.x;
+        ggrid.x = grid.x * (unsigned)grp->n;
+    }
 #define AQ_WGV(MM, NN, CC, JJ)                                                                                                 \
-    {                                                                                                                          \
+    if (grp) {                                                                                                                 \
+        auto kern = conv_wgrad_group_kernel<MM, NN, CC, JJ>;                                                                   \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, ggrid, dim3(512), lds, st, a, gg);                                                            \
+    } else {                                                                                                                   \
         auto kern = conv_wgrad_kernel<MM, NN, CC, JJ>;                                                                         \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                                 \
     }
-#define AQ_WG(MM, NN)                                                                                                          \
-    {                                                                                                                          \
-        auto kern = conv_wgrad_kernel<MM, NN, 0, 1>;                                                                                 \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                                 \
-    }
+#define AQ_WG(MM, NN) AQ_WGV(MM, NN, 0, 1)
     if (variant == 1) AQ_WGV(1, 9, 4, 4)
     else if (variant == 2) AQ_WGV(2, 9, 4, 9)
     else if (variant == 3) AQ_WGV(1, 18, 8, 3)

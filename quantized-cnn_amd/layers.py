@@ -160,6 +160,27 @@ def _fused_backward_ok(dW_slot):
     return FUSE_CONV_BACKWARD and _wgrad_deferred is not None and dW_slot is not None and _wgrad_stream is None
 
 
+# With deferral on (and no side stream), the first-stage kernels themselves can wait for the end of the backward pass
+# too: the entry then carries (None, slot, None, x, dy, stride, ks, pad) and run_deferred_wgrads launches the layers
+# of one shape together (ops.conv_wgrad_partial_group), e.g. the six 3x3 convolutions of a ResNet-20 stage in one
+# launch instead of six that each fill a fraction of the chip.
+DEFER_WGRAD_KERNELS = True
+
+
+def run_deferred_wgrads(jobs):
+    """Launch the first-stage kernels of the entries that still lack them, grouped by shape; jobs is updated in place
+    to (workspace, slot, nslab, x, dy) entries ready for ops.conv_wgrad_reduce."""
+    groups = {}
+    for i, job in enumerate(jobs):
+        if job[0] is None:
+            _, _, _, x, dy, stride, ks, pad = job
+            groups.setdefault((tuple(x.shape), tuple(dy.shape), stride, ks, pad), []).append(i)
+    for (_, _, stride, ks, pad), idx in groups.items():
+        res = ops.conv_wgrad_partial_group([jobs[i][3] for i in idx], [jobs[i][4] for i in idx], stride, ks, pad)
+        for i, (ws, nslab) in zip(idx, res):
+            jobs[i] = (ws, jobs[i][1], nslab, jobs[i][3], jobs[i][4])
+
+
 def _weight_grad(x, dy, stride, dW_slot, ks=3, pad=1):
     """dW of a convolution for autograd, or None when it is left in dW_slot by the batched reduction at
     the end of the backward pass (nothing is handed to autograd then: it would clone the slot into the
@@ -169,6 +190,9 @@ def _weight_grad(x, dy, stride, dW_slot, ks=3, pad=1):
             _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
             with torch.cuda.stream(_wgrad_stream):
                 ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
+        elif DEFER_WGRAD_KERNELS:
+            _wgrad_deferred.append((None, dW_slot, None, x, dy, stride, ks, pad))
+            return None
         else:
             ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
         _wgrad_deferred.append((ws, dW_slot, nslab, x, dy))

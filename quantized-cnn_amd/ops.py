@@ -304,6 +304,26 @@ def conv_wgrad_partial(x, dy, stride=1, ks=3, pad=1):
     return ws, nslab.value
 
 
+def conv_wgrad_partial_group(xs, dys, stride=1, ks=3, pad=1):
+    """conv_wgrad_partial for several layers of ONE shape in one launch per 8 layers -> list of (workspace, nslab)."""
+    if not xs:
+        return []
+    x0, Cout = xs[0], dys[0].shape[1]
+    for x, dy in zip(xs, dys):
+        if tuple(x.shape) != tuple(x0.shape) or tuple(dy.shape) != conv_out_shape(x0.shape, Cout, stride, ks, pad):
+            raise ValueError("conv_wgrad_partial_group: layers of different shapes (%s / %s against %s)" % (tuple(x.shape), tuple(dy.shape), tuple(x0.shape)))
+    dims = _conv_dims(x0.shape, Cout, stride, ks, pad)
+    nbytes = _lib.lib().aq_conv_wgrad_workspace_bytes(*dims)
+    n = len(xs)
+    wss = [torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x0.device) for _ in range(n)]
+    ax = (C.c_void_p * n)(*[_lib.ptr(x, name="x") for x in xs])
+    ady = (C.c_void_p * n)(*[_lib.ptr(dy, name="dy") for dy in dys])
+    aws = (C.c_void_p * n)(*[w.data_ptr() for w in wss])
+    nslab = C.c_int(0)
+    _lib.check(_lib.lib().aq_conv_wgrad_partial_group(ax, ady, aws, n, *dims, nbytes, C.byref(nslab), _lib.stream()))
+    return [(w, nslab.value) for w in wss]
+
+
 def conv_wgrad_reduce(jobs):
     """jobs: list of (workspace, dW tensor, nslab) from conv_wgrad_partial; one launch per 32 jobs."""
     if not jobs:

@@ -314,6 +314,7 @@ class FusedTrainStep:
             layers.defer_wgrad_reductions(*prev)
         if self.overlap_wgrad:
             torch.cuda.current_stream().wait_stream(self._side)  # join: all weight-gradient slabs written
+        layers.run_deferred_wgrads(jobs)  # first-stage kernels that waited for the end of the pass, one launch per layer shape
         ops.conv_wgrad_reduce(jobs)  # the slab sums of all quantized convolutions in one launch
         del jobs
         if self.stem_slot is not None:

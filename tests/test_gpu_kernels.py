@@ -563,7 +563,8 @@ def test_bnconv_equals_separate_kernels(shape):
     ws, nslab = ops.bnconv_wgrad_partial(x, g, b, mean, rstd, dy, s)
     dW = torch.empty_like(W)
     ops.conv_wgrad_reduce([(ws, dW, nslab)])
-    assert torch.equal(dW, ops.conv_wgrad(z, dy, s))
+    want = ops.conv_wgrad(z, dy, s)  # (shapes with 16-channel multiples run on another kernel there: same sums, other order)
+    assert (dW - want).abs().max().item() <= 2e-6 * want.abs().max().item()
 
 
 def test_bnconv_unsupported_shapes_are_reported():
@@ -679,7 +680,7 @@ def test_dgrad_epilogue_unsupported_shape_falls_back():
 @pytest.mark.parametrize("with_bn", [False, True])
 def test_conv_backward_one_call_equals_separate_calls(shape, with_bn):
     """aq_conv_bwd (input gradient and weight-gradient slabs side by side in one launch where a kernel pair
-    exists) gives the bits of aq_conv_dgrad[_bn] and aq_conv_wgrad_partial."""
+    exists) gives the bits of aq_conv_dgrad[_bn] and the sums of aq_conv_wgrad_partial."""
     cin, cout, s, H, N = shape
     rs = np.random.RandomState(sum(shape) + 3 * with_bn)
     Wd = 36 if H == 40 else H
@@ -699,7 +700,9 @@ def test_conv_backward_one_call_equals_separate_calls(shape, with_bn):
         dz, sums, ws, nslab = ops.conv_backward(dy, W, z, s, bn=bn)
         dW = torch.empty_like(W)
         ops.conv_wgrad_reduce([(ws, dW, nslab)])
-        assert torch.equal(dz, dz_ref) and torch.equal(dW, dW_ref)
+        assert torch.equal(dz, dz_ref)
+        # (the separate weight gradient of shapes with 16-channel multiples runs on another kernel: same sums, other order)
+        assert (dW - dW_ref).abs().max().item() <= 2e-6 * dW_ref.abs().max().item()
         assert (sums is None) == (sums_ref is None)
         if sums is not None:  # the sums may be split over another number of workgroups: compare what they merge to
             got = ops.bn_relu_backward(dz, xb, g, b, mean, rstd, dgrad_sums=sums)
@@ -849,3 +852,30 @@ def test_conv_dgrad_adds_the_shortcut_gradient(shape):
     assert torch.equal(ops.conv_dgrad(dy, W, xs, s, res=res), want)
     with pytest.raises(ValueError, match="excludes bn"):
         ops.conv_dgrad(dy, W, xs, s, res=res, bn=(res, None, None, None, None))
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 1, 32, 5), (32, 64, 2, 16, 3), (64, 64, 1, 8, 9), (128, 64, 1, 14, 2), (3, 16, 1, 32, 2), (20, 24, 1, 9, 3)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_grouped_weight_gradient_equals_single_launches(shape):
+    """aq_conv_wgrad_partial_group (layers of one shape in one launch; what the fused training step runs at the end of
+    the backward pass) against one aq_conv_wgrad per layer (autograd of adp_qtz_fan.py:574-601): the same sums, cut
+    into fewer slabs when several layers share the launch, so equal within fp32 summation order (2e-6 of the largest
+    element; bit-equal on the kernels whose slab count does not depend on the group), and reproducible bit for bit."""
+    cin, cout, stride, H, nl = shape
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xs = [torch.randn(6, cin, H, H, device=DEV, generator=g) for _ in range(nl)]
+    Ho = (H + 2 - 3) // stride + 1
+    dys = [torch.randn(6, cout, Ho, Ho, device=DEV, generator=g) for _ in range(nl)]
+
+    def grouped():
+        res = ops.conv_wgrad_partial_group(xs, dys, stride)
+        outs = [torch.empty(cout, cin, 3, 3, device=DEV) for _ in range(nl)]
+        ops.conv_wgrad_reduce([(ws, o, ns) for (ws, ns), o in zip(res, outs)])
+        return outs
+    outs, again = grouped(), grouped()
+    for x, dy, o, o2 in zip(xs, dys, outs, again):
+        want = ops.conv_wgrad(x, dy, stride)
+        assert (o - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+        assert torch.equal(o, o2)
+        if cin % 16 or cout % 16:
+            assert torch.equal(o, want)

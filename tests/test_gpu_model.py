@@ -399,7 +399,7 @@ def test_eval_mode_batchnorm_uses_running_statistics():
 
 
 def test_bn_fused_into_conv_gives_the_same_training_step():
-    """layers.FUSE_BN_INTO_CONV: same operation sequence, so logits, loss and every gradient are bit-equal
+    """layers.FUSE_BN_INTO_CONV: same operation sequence, so logits, loss and buffers are bit-equal and every gradient agrees
     (with the statistics pass as the source of the batch statistics on both sides: the fused kernel
     merges that pass's partials, not the ones a convolution's epilogue leaves behind; likewise the
     backward reductions)."""
@@ -425,7 +425,11 @@ def test_bn_fused_into_conv_gives_the_same_training_step():
             layers.CONV_EMITS_BN_STATS = True
             layers.COUPLE_BN_BACKWARD = True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    for a, b in zip(outs[0][2] + outs[0][3], outs[1][2] + outs[1][3]):
+    # gradients: the fused weight gradient runs on the small-channel kernel, the separate one of the 16-channel-multiple
+    # layers on the many-channel kernel (same sums in another order); everything upstream is the same bits
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert (a - b).abs().max().item() <= 2e-6 * max(a.abs().max().item(), 1e-30)
+    for a, b in zip(outs[0][3], outs[1][3]):
         assert torch.equal(a, b)
 
 
