@@ -1977,7 +1977,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgC16Args a, 
 {
     constexpr int T2 = KS * KS, CSX = 16 * NG + 4, CGX = 4 * NG, ROW = 16 * NG * T2, TP = ROW + 4;
     constexpr int PW = 4 / CW, WC_CSA = 16 * CW + 4, WC_MAXA = 2 * CW;  // dy staging items per thread: 4 * CW * slots <= 256 * WC_MAXA
-    constexpr int MAXX = KS == 1 ? 8 : 10;  // x staging items per thread
+    constexpr int MAXX = KS == 1 ? 8 : 5 * NG;  // x staging items per thread: 4 * NG * image pixels <= 256 * MAXX (the plan keeps the image within 320 pixels)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int nslots = a.nkb * 16;
@@ -2881,10 +2881,11 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     a.nW = Cout * Cin * ks * ks;
     const int gy = (Cout + 16 * CW - 1) / (16 * CW), gz = Cin / (16 * NG);
     if (gy >= 65536 || gz >= 65536) return p;
-    // slabs: one round of workgroups over the chip's 512 places for all layers of the launch together (every slab costs
+    // slabs: one round of workgroups over the chip's places for all layers of the launch together (every slab costs
     // a pass over dW and a prologue), at least 2 tiles per slab, at most 256 slabs
     const long long per = (long long)gy * gz * std::max(1, nlayers);
-    long long want = (512 + per - 1) / per;
+    const long long places = CW == 4 ? 512 : 768;  // (the 16- and 32-channel forms need fewer registers: three workgroups per CU)
+    long long want = (places + per - 1) / per;
     want = std::max<long long>(1, std::min<long long>(std::min<long long>(want, 256), (a.ntiles + 1) / 2));
     a.nslab = (int)std::min<long long>(want, a.ntiles);
     p.grid = dim3((unsigned)a.nslab, (unsigned)gy, (unsigned)gz);
