@@ -148,6 +148,32 @@ def kernel_rooflines(quick):
             more.append({"bound": "mfma", "kernel": "%s %d->%d s%d %dx%d N=%d" % (name, cin, cout, s, H, H, BATCH),
                          "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+        # the weight gradients as the training step runs them: the layers of one shape together at the end of the backward
+        # pass (conv_wgrad_partial_group + the batched slab reduction); per-layer average
+        nl = {(16, 16): 6, (32, 32): 5, (64, 64): 5}.get((cin, cout), 1)
+        if nl > 1:
+            xs = [torch.randn_like(x) for _ in range(nl)]
+            dys = [torch.randn_like(dy) for _ in range(nl)]
+            outs = [torch.empty(cout, cin, 3, 3, device=dev) for _ in range(nl)]
+
+            def grouped():
+                res = ops.conv_wgrad_partial_group(xs, dys, s)
+                ops.conv_wgrad_reduce([(ws, o, ns) for (ws, ns), o in zip(res, outs)])
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                grouped()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(10):
+                        grouped()
+            torch.cuda.current_stream().wait_stream(st)
+            t = event_time(gr.replay, 5, 2) / (10 * nl)
+            more.append({"bound": "mfma", "kernel": "conv_wgrad %d->%d s%d %dx%d N=%d, %d layers per launch as in the training step (per layer)" % (
+                cin, cout, s, H, H, BATCH, nl), "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+            del xs, dys, outs
     # ---- kernels of the quantiser modes and shapes that have no reference code (parity unpinned) ----
     torch.cuda.empty_cache()
     n = 250_000_000 if not quick else 25_000_000
