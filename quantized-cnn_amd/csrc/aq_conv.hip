@@ -1695,6 +1695,7 @@ struct WgradGroup {
     const float *x[WGRAD_GROUP_MAX], *dy[WGRAD_GROUP_MAX];
     float *part[WGRAD_GROUP_MAX];
     int n, gx;
+    int total;  // layers of the whole call (it may take several launches of n <= WGRAD_GROUP_MAX): what the slab count is planned for
 };
 template <int MG, int NG, int CH4, int J>
 __global__ __launch_bounds__(512) void conv_wgrad_group_kernel(const WgradArgs a, const WgradGroup g)
@@ -2865,7 +2866,7 @@ static WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks,
     double best = 0.0;
     for (int th = 1; th <= a.Ho && th * a.PW4 <= 128; ++th) {
         const int xr = (th - 1) * stride + ks;
-        if (ks == 3 && (4 * NG * xr * a.XP > 256 * 10 || xr * a.XP * CSX > 300 * 36)) break;
+        if (ks == 3 && (xr * a.XP > 320 || xr * a.XP * CSX > 300 * 36)) break;  // staging: 4 * NG * pixels <= 256 * (5 * NG) items; LDS
         const int nkb = (th * a.PW4 + 15) / 16, ty = (a.Ho + th - 1) / th;
         const double util = (double)a.Ho * a.Wo / ((double)ty * nkb * 16) * (1.0 - 0.2 / nkb);  // (fixed cost per tile: barriers, staging)
         if (util > best) {
@@ -3010,6 +3011,7 @@ int aq_conv_wgrad_partial_group(const float *const *x, const float *const *dy, v
     for (int base = 0; base < nlayers; base += WGRAD_GROUP_MAX) {
         WgradGroup g = {};
         g.n = std::min(WGRAD_GROUP_MAX, nlayers - base);
+        g.total = nlayers;
         for (int l = 0; l < g.n; ++l) {
             g.x[l] = x[base + l]; g.dy[l] = dy[base + l]; g.part[l] = static_cast<float *>(workspace[base + l]);
         }
@@ -3119,7 +3121,7 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
     if (!bn) {
-        WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad, grp ? grp->n : 1);
+        WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad, grp ? std::max(grp->n, grp->total) : 1);
         if (cp.use) {
             AQ_REQUIRE(workspace && workspace_bytes >= cp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", cp.ws_bytes,
                        workspace_bytes);
