@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--quick", action="store_true", help="smaller roofline tensor and CPU sample (development)")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline and cpu_baseline measurements")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient groups on a second stream beside the rest of the backward pass")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU form of the step (two HIP graphs around an RCCL all-reduce) even on one GPU")
     args = ap.parse_args()
@@ -319,7 +320,8 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1000 + rank)
     x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
     y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
-    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None)
+    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None,
+                          overlap_wgrad=args.overlap_wgrad)
 
     step(x, y)
     bufs = step.static_inputs()

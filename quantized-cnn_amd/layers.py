@@ -167,14 +167,18 @@ def _fused_backward_ok(dW_slot):
 DEFER_WGRAD_KERNELS = True
 
 
-def run_deferred_wgrads(jobs):
-    """Launch the first-stage kernels of the entries that still lack them, grouped by shape; jobs is updated in place
-    to (workspace, slot, nslab, x, dy) entries ready for ops.conv_wgrad_reduce."""
+def _job_key(job):
+    _, _, _, x, dy, stride, ks, pad = job
+    return (tuple(x.shape), tuple(dy.shape), stride, ks, pad)
+
+
+def run_deferred_wgrads(jobs, skip_key=None):
+    """Launch the first-stage kernels of the entries that still lack them, grouped by shape (all but those of shape
+    skip_key); jobs is updated in place to (workspace, slot, nslab, x, dy) entries ready for ops.conv_wgrad_reduce."""
     groups = {}
     for i, job in enumerate(jobs):
-        if job[0] is None:
-            _, _, _, x, dy, stride, ks, pad = job
-            groups.setdefault((tuple(x.shape), tuple(dy.shape), stride, ks, pad), []).append(i)
+        if job[0] is None and _job_key(job) != skip_key:
+            groups.setdefault(_job_key(job), []).append(i)
     for (_, _, stride, ks, pad), idx in groups.items():
         res = ops.conv_wgrad_partial_group([jobs[i][3] for i in idx], [jobs[i][4] for i in idx], stride, ks, pad)
         for i, (ws, nslab) in zip(idx, res):
@@ -186,13 +190,20 @@ def _weight_grad(x, dy, stride, dW_slot, ks=3, pad=1):
     the end of the backward pass (nothing is handed to autograd then: it would clone the slot into the
     leaf's .grad)."""
     if _wgrad_deferred is not None and dW_slot is not None:
+        if DEFER_WGRAD_KERNELS:
+            job = (None, dW_slot, None, x, dy, stride, ks, pad)
+            if _wgrad_stream is not None and any(j[0] is None and _job_key(j) != _job_key(job) for j in _wgrad_deferred):
+                # a layer of another shape: the group collected so far is complete (the backward pass leaves a residual
+                # stage) and runs on the side stream, beside the rest of the pass: one cross-stream edge per group
+                _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy of every collected layer is ready
+                with torch.cuda.stream(_wgrad_stream):
+                    run_deferred_wgrads(_wgrad_deferred)
+            _wgrad_deferred.append(job)
+            return None
         if _wgrad_stream is not None:
             _wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy is ready
             with torch.cuda.stream(_wgrad_stream):
                 ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
-        elif DEFER_WGRAD_KERNELS:
-            _wgrad_deferred.append((None, dW_slot, None, x, dy, stride, ks, pad))
-            return None
         else:
             ws, nslab = ops.conv_wgrad_partial(x, dy, stride, ks, pad)
         _wgrad_deferred.append((ws, dW_slot, nslab, x, dy))

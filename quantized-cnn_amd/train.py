@@ -225,10 +225,12 @@ class FusedTrainStep:
         on one GPU.
         fuse_adam: apply optimizer_prim's Adam update of p_c inside the synthesis-gradient kernel (the
         optimizer object keeps its state tensors and state_dict format; its step() is not called).
-        overlap_wgrad: run the weight-gradient kernels on a second HIP stream beside the rest of the
-        backward pass (a parallel branch of the captured graph).  Off by default: replaying a graph with
-        one cross-stream edge per layer measured slower on MI355X / ROCm 7.2 (77.0k against 82.2k img/s)
-        than the single-stream chain, although the kernels themselves overlap."""
+        overlap_wgrad: run the weight-gradient launches (one per group of layers of a shape, started when the backward
+        pass leaves their residual stage) on a second HIP stream beside the rest of the backward pass (a parallel
+        branch of the captured graph).  Off by default: measured slower on MI355X / ROCm 7.2 than the single-stream
+        chain that runs all groups after the pass (108.2k against 110.2k img/s in one session; with one
+        cross-stream edge per layer, before the layers were grouped, 77.0k against 82.2k): the input-gradient
+        kernels beside them already occupy every CU, so the groups take their time from the chain."""
         self.overlap_wgrad = bool(overlap_wgrad)
         self._side = torch.cuda.Stream() if self.overlap_wgrad else None
         self.model, self.config, self.module, self.dp = model, config, module, dp
@@ -312,9 +314,9 @@ class FusedTrainStep:
             logits.backward(dlogits)
         finally:
             layers.defer_wgrad_reductions(*prev)
+        layers.run_deferred_wgrads(jobs)  # first-stage kernels that waited for the end of the pass, one launch per layer shape
         if self.overlap_wgrad:
             torch.cuda.current_stream().wait_stream(self._side)  # join: all weight-gradient slabs written
-        layers.run_deferred_wgrads(jobs)  # first-stage kernels that waited for the end of the pass, one launch per layer shape
         ops.conv_wgrad_reduce(jobs)  # the slab sums of all quantized convolutions in one launch
         del jobs
         if self.stem_slot is not None:
