@@ -110,7 +110,7 @@ def kernel_rooflines(quick):
     dp31 = [dp[0].view(-1)[:rows * L31].view(rows, L31)]
     t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 10)
     t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 10)
-    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 0, false, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 0, false, false> (L = 31)", t31b, 8 * L31 + 4)):
+    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 3, false, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 3, false, false> (L = 31)", t31b, 8 * L31 + 4)):
         aa = rows * bpr / tt / 1e9
         more.append({"bound": "hbm", "kernel": nm, "achieved": round(aa, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(aa / HBM_PEAK_GBS, 4),
                      "bytes_per_row": bpr, "rows_per_launch": rows, "avg_launch_ms": round(tt * 1e3, 4)})

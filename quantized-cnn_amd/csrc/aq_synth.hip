@@ -52,21 +52,26 @@ struct SegTab {
 
 // MEM: 0 = rows only 4-byte aligned (L != 4G or unaligned base), 1 = 16-byte vector access,
 // 2 = 16-byte vector access with the nontemporal (streaming) cache policy, chosen by the host for
-// tensors larger than the last-level cache: +7 % (forward) / +10 % (backward) at 1 GB.
+// tensors larger than the last-level cache: +7 % (forward) / +10 % (backward) at 1 GB; 3 = the rows of 0 with the
+// streaming policy.  The policy is a template parameter, never a run-time flag: two branches that differ only in the
+// nontemporal marking are merged by the compiler into one plain access.
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f4 f4_a4 __attribute__((aligned(4)));  // a 16-byte access at a 4-byte-aligned address
+constexpr bool mem_vec(int mem) { return mem == 1 || mem == 2; }
+constexpr bool mem_nt(int mem) { return mem >= 2; }
 
 template <int G, int MEM>
 __device__ __forceinline__ void load_elems(const float *__restrict__ p, long long r, int L, int j, float (&v)[4])
 {
-    if constexpr (MEM != 0) {
+    if constexpr (mem_vec(MEM)) {
         const f4 *src = reinterpret_cast<const f4 *>(p) + (r * G + j);
-        const f4 t = (MEM == 2) ? __builtin_nontemporal_load(src) : *src;
+        const f4 t = mem_nt(MEM) ? __builtin_nontemporal_load(src) : *src;
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
         const float *a = p + r * (long long)L + 4 * j;
         if (4 * j + 3 < L) {
-            float4 t;
-            __builtin_memcpy(&t, a, 16);  // rows are only 4-byte aligned here
+            const f4_a4 *src = reinterpret_cast<const f4_a4 *>(a);  // rows are only 4-byte aligned here
+            const f4 t = mem_nt(MEM) ? __builtin_nontemporal_load(src) : *src;
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
@@ -78,10 +83,10 @@ __device__ __forceinline__ void load_elems(const float *__restrict__ p, long lon
 template <int G, int MEM>
 __device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, int L, int j, const float (&v)[4])
 {
-    if constexpr (MEM != 0) {
+    if constexpr (mem_vec(MEM)) {
         f4 *dst = reinterpret_cast<f4 *>(p) + (r * G + j);
         const f4 t = {v[0], v[1], v[2], v[3]};
-        if (MEM == 2) __builtin_nontemporal_store(t, dst);
+        if (mem_nt(MEM)) __builtin_nontemporal_store(t, dst);
         else *dst = t;
     } else {
         float *a = p + r * (long long)L + 4 * j;
@@ -106,7 +111,7 @@ template <int G, int MEM>
 __device__ __forceinline__ void load_rows8(const float *__restrict__ p, long long R0, long long rows, int L, int j, int gq, bool fast, float (&v)[8][4])
 {
     constexpr int RPP = 64 / G;
-    if (MEM == 0 && fast) {
+    if (!mem_vec(MEM) && fast) {
         f4 t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -114,7 +119,10 @@ __device__ __forceinline__ void load_rows8(const float *__restrict__ p, long lon
             const float *a = p + (R0 + gq) * (long long)L + 4 * j;
             const long long step = (long long)RPP * L;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) __builtin_memcpy(&t[u], a + u * step, 16);
+            for (int u = 0; u < 8; ++u) {
+                const f4_a4 *src = reinterpret_cast<const f4_a4 *>(a + u * step);
+                t[u] = mem_nt(MEM) ? __builtin_nontemporal_load(src) : *src;
+            }
         }
         const bool k1 = 4 * j + 1 < L, k2 = 4 * j + 2 < L, k3 = 4 * j + 3 < L;
 #pragma unroll
@@ -141,7 +149,7 @@ __device__ __forceinline__ void load_rows8(const float *__restrict__ p, long lon
 // (uniform); buf = this wavefront's 256 floats of LDS; called by all lanes.
 template <int G, bool FULL>  // FULL: all 64 / G rows present and their floats a multiple of 4 (no scalar tail)
 __device__ __forceinline__ void store_rows_staged(float *__restrict__ p, long long R0, int nrows, int L, int j, int gq, int lane, const float (&v)[4],
-                                                  float *buf, bool stream)
+                                                  float *buf, const bool stream)
 {
     __builtin_amdgcn_wave_barrier();  // (scheduling only: LDS operations of one wavefront execute in order)
     // Four unpredicated 4-byte writes per lane, element 3 first: the lane at the ragged row end spills up to 3 values
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                     const float thr = group_bcast<G, ub + u>(my_thr);
                     float pv[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pv[k] = (MEM != 0 || valid[k]) ? v[u][k] : -__builtin_inff();
+                    for (int k = 0; k < 4; ++k) pv[k] = (mem_vec(MEM) || valid[k]) ? v[u][k] : -__builtin_inff();
                     uint32_t bk = float_key(pv[0]), bi = 4 * j;
 #pragma unroll
                     for (int k = 1; k < 4; ++k) {
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float ex = EXACT ? expf_spec(beta * (v[u][k] * rn)) : exp2_hw(v[u][k] * rn);
-                    e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
+                    e[k] = (mem_vec(MEM) || valid[k]) ? ex : 0.0f;
                 }
                 const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
                 const float num = group_sum<G>(chain_dot(e, q4));
@@ -363,10 +371,10 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     float *__restrict__ part = tab.s[si].part;
     const long long rows = tab.s[si].rows;
     const int L = tab.s[si].L;
-    __shared__ __attribute__((aligned(16))) float stage_all[MEM == 0 ? WAVES * STAGE_FLOATS : 4];
-    float *stage = stage_all + (MEM == 0 ? wave * STAGE_FLOATS : 0);
-    const bool rag = MEM == 0 && tab.s[si].rag != 0;
-    const bool rag_stream = tab.s[si].rag == 2;
+    __shared__ __attribute__((aligned(16))) float stage_all[!mem_vec(MEM) ? WAVES * STAGE_FLOATS : 4];
+    float *stage = stage_all + (!mem_vec(MEM) ? wave * STAGE_FLOATS : 0);
+    const bool rag = !mem_vec(MEM) && tab.s[si].rag != 0;
+    constexpr bool rag_stream = mem_nt(MEM);
 
     const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
     const long long row_begin = wt * tab.K * ROWS_IT;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                     for (int k = 0; k < 4; ++k) {
                         pn[k] = v[u][k] * rn;
                         const float ex = EXACT ? expf_spec(beta * pn[k]) : exp2_hw(pn[k] * (beta * LOG2E));
-                        e[k] = (MEM != 0 || valid[k]) ? ex : 0.0f;
+                        e[k] = (mem_vec(MEM) || valid[k]) ? ex : 0.0f;
                     }
                     const float den = group_sum<G>(((e[0] + e[1]) + e[2]) + e[3]);
                     const float num = group_sum<G>(chain_dot(e, q4));
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                 });
             });
         };
-        if constexpr (MEM == 0) {
+        if constexpr (!mem_vec(MEM)) {
             if (rag && fast_rows) batch(std::true_type{});
             else batch(std::false_type{});
         } else {
@@ -672,6 +680,7 @@ static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &ta
 #define AQ_LAUNCH_G(GG)                      \
     if (mem == 2) { AQ_LAUNCH(GG, 2) }       \
     else if (mem == 1) { AQ_LAUNCH(GG, 1) }  \
+    else if (mem == 3) { AQ_LAUNCH(GG, 3) }  \
     else { AQ_LAUNCH(GG, 0) }
     if (G == 8) { AQ_LAUNCH_G(8) }
     else if (G == 16) { AQ_LAUNCH_G(16) }
@@ -730,7 +739,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             bool hard = false, wants_w = false;  // wants_w: some layer of the launch asks for W or sum W^2
             auto flush = [&]() {
                 if (tab.nseg)
-                    launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : 0, hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st,
+                    launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : (stream_policy ? 3 : 0), hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st,
                                       hard && !wants_w);
                 tab.nseg = 0;
                 nblocks = 0;
@@ -754,7 +763,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                 if (BWD && !v && (s.L & 3) != 0 && ((64 / G) * s.L) % 4 == 0) {
                     bool al = (((uintptr_t)s.dp_c & 15) == 0);
                     if (adam) al = al && (((uintptr_t)s.p_c | (uintptr_t)s.adam_m | (uintptr_t)s.adam_v) & 15) == 0;
-                    if (al) d.rag = stream_policy ? 2 : 1;
+                    if (al) d.rag = 1;
                 }
                 hard = hard || s.idx != nullptr || s.W_hard != nullptr;
                 wants_w = wants_w || s.W != nullptr || d.part != nullptr;

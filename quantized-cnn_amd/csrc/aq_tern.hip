@@ -26,6 +26,7 @@ namespace aq {
 
 constexpr int TERN_MAX_SEGS = 32;
 constexpr int TERN_ELEMS_PER_WAVE = 64 * 4 * 8;  // 8 coalesced 16-byte loads per lane
+constexpr int TERN_ELEMS_PER_WAVE_2IN = 64 * 4 * 4;  // kernels with two input streams: 4 loads per lane and stream (8 in flight)
 
 struct TernSegDev {
     const float *w;
@@ -45,7 +46,7 @@ struct TernSegDev {
 };
 struct TernTab {
     int nseg;
-    int nt;  // tensors beyond the last-level cache: streaming (nontemporal) loads and stores
+    int nt;  // tensors beyond the last-level cache: the host launches the streaming (nontemporal) instantiations
     TernSegDev s[TERN_MAX_SEGS];
 };
 
@@ -82,28 +83,26 @@ __device__ __forceinline__ void wave_partials(const float (&vals)[F], float *par
     }
 }
 
-// element range [e0, e1) of wavefront `wt` of a layer, and this lane's share: elements e0 + 256*u + 4*lane + k
+// element range [e0, e1) of wavefront `wt` of a layer, and this lane's share: elements e0 + 256*u + 4*lane + k.
+// NT is a template parameter on purpose: with a run-time flag the two branches hold the same loads, the compiler merges
+// them and the merged load loses its nontemporal marking (plain loads: 6.1 instead of 6.9 TB/s on a read-only pass).
 typedef float tern_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load8(const float *__restrict__ w, long long e0, long long n, int lane, float (&v)[8][4], bool vec, bool nt = false)
+template <int U, bool NT>
+__device__ __forceinline__ void load_run(const float *__restrict__ w, long long e0, long long n, int lane, float (&v)[U][4], bool vec)
 {
-    if (vec && e0 + TERN_ELEMS_PER_WAVE <= n) {  // whole wavefront inside the tensor (uniform): eight loads issued back to back
+    if (vec && e0 + 256 * U <= n) {  // whole wavefront inside the tensor (uniform): U loads issued back to back
         const tern_f4 *src = reinterpret_cast<const tern_f4 *>(w + e0) + lane;
-        tern_f4 t[8];
-        if (nt) {
+        tern_f4 t[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(src + 64 * u);
-        } else {
+        for (int u = 0; u < U; ++u) t[u] = NT ? __builtin_nontemporal_load(src + 64 * u) : src[64 * u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = src[64 * u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             v[u][0] = t[u].x; v[u][1] = t[u].y; v[u][2] = t[u].z; v[u][3] = t[u].w;
         }
         return;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
         const long long e = e0 + 256 * u + 4 * lane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[u][k] = e + k < n ? w[e + k] : 0.0f;
@@ -111,6 +110,7 @@ __device__ __forceinline__ void load8(const float *__restrict__ w, long long e0,
 }
 
 // A: partials (sum |w|, max |w|) per wavefront
+template <bool NT>
 __global__ __launch_bounds__(256) void tern_absstat_kernel(const TernTab tab)
 {
     const int si = tern_segment(tab);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void tern_absstat_kernel(const TernTab tab)
     const int wt = blk * 4 + wave;
     const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;  // (wavefronts beyond the layer load nothing: all zeros)
     float v[8][4];
-    load8(s.w, e0, s.n, lane, v, ((uintptr_t)s.w & 15) == 0, tab.nt != 0);
+    load_run<8, NT>(s.w, e0, s.n, lane, v, ((uintptr_t)s.w & 15) == 0);
     float sum = 0.0f, mx = 0.0f;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void tern_delta_kernel(const TernTab tab, con
 }
 
 // C: codes (+ packed codes, decoded weights when the codebook is already known) and partials of the second reduction
-template <bool TTQ>
+template <bool TTQ, bool NT>
 __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
 {
     const int si = tern_segment(tab);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
     }
     float v[8][4];
     const bool vec = ((uintptr_t)s.w & 15) == 0;
-    load8(s.w, e0, s.n, lane, v, vec, tab.nt != 0);
+    load_run<8, NT>(s.w, e0, s.n, lane, v, vec);
     float sabs = 0.0f, npos = 0.0f, nneg = 0.0f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -246,8 +246,10 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
             o[k] = c == 1u ? pos : (c == 2u ? -neg : 0.0f);
         }
         if (s.codes) {
-            if (e + 3 < s.n && ((uintptr_t)s.codes & 3) == 0) *reinterpret_cast<unsigned *>(s.codes + e) = c4;
-            else {
+            if (e + 3 < s.n && ((uintptr_t)s.codes & 3) == 0) {
+                if (NT) __builtin_nontemporal_store(c4, reinterpret_cast<unsigned *>(s.codes + e));
+                else *reinterpret_cast<unsigned *>(s.codes + e) = c4;
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (e + k < s.n) s.codes[e + k] = (uint8_t)(c4 >> (8 * k));
@@ -270,8 +272,11 @@ __global__ __launch_bounds__(256) void tern_emit_kernel(const TernTab tab)
             }
         }
         if (TTQ && s.wt) {
-            if (vec && ((uintptr_t)s.wt & 15) == 0 && e + 3 < s.n) *reinterpret_cast<float4 *>(s.wt + e) = make_float4(o[0], o[1], o[2], o[3]);
-            else {
+            if (vec && ((uintptr_t)s.wt & 15) == 0 && e + 3 < s.n) {
+                const tern_f4 t = {o[0], o[1], o[2], o[3]};
+                if (NT) __builtin_nontemporal_store(t, reinterpret_cast<tern_f4 *>(s.wt + e));
+                else *reinterpret_cast<tern_f4 *>(s.wt + e) = t;
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (e + k < s.n) s.wt[e + k] = o[k];
@@ -336,28 +341,29 @@ __global__ __launch_bounds__(256) void tern_decode_kernel(const TernTab tab)
 // backward.  MODE 0 (TWN): dw = dwt (straight through).  MODE 1 (TTQ): dw = pos * dwt where w > delta, neg * dwt where
 // w < -delta, dwt in between; partials of sum dwt over the positives and over the negatives.  MODE 2 (INQ):
 // dw = dwt where mask != 0, else 0.
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
 {
+    constexpr int U = MODE == 1 ? 4 : 8;  // loads per lane and input stream: eight in flight either way
     const int si = tern_segment(tab);
     const TernSegDev &s = tab.s[si];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = (int)blockIdx.x - s.blk0;
     const int wt = blk * 4 + wave;
-    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    const long long e0 = (long long)wt * (256 * U);
     float delta = 0.0f, pos = 1.0f, neg = 1.0f;
     if (MODE == 1) {
         delta = s.stats[0];
         pos = s.wp[0];
         neg = s.wn[0];
     }
-    float g[8][4], v[8][4];
+    float g[U][4], v[U][4];
     const bool vec = (((uintptr_t)s.dwt | (uintptr_t)s.dw | (uintptr_t)s.w) & 15) == 0;
-    load8(s.dwt, e0, s.n, lane, g, vec, tab.nt != 0);
-    if (MODE == 1) load8(s.w, e0, s.n, lane, v, vec, tab.nt != 0);
+    load_run<U, NT>(s.dwt, e0, s.n, lane, g, vec);
+    if (MODE == 1) load_run<U, NT>(s.w, e0, s.n, lane, v, vec);
     float sp = 0.0f, sn = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
         const long long e = e0 + 256 * u + 4 * lane;
         float o[4];
 #pragma unroll
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void tern_bwd_kernel(const TernTab tab)
         }
         if (vec && e + 3 < s.n) {
             const tern_f4 t = {o[0], o[1], o[2], o[3]};
-            if (tab.nt) __builtin_nontemporal_store(t, reinterpret_cast<tern_f4 *>(s.dw + e));
+            if (NT) __builtin_nontemporal_store(t, reinterpret_cast<tern_f4 *>(s.dw + e));
             else *reinterpret_cast<tern_f4 *>(s.dw + e) = t;
         } else {
 #pragma unroll
@@ -449,16 +455,18 @@ __global__ __launch_bounds__(256) void inq_partition_kernel(float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------- host side
 
-static inline int tern_waves(long long n) { return (int)((n + TERN_ELEMS_PER_WAVE - 1) / TERN_ELEMS_PER_WAVE); }
+static inline int tern_waves(long long n, int epw) { return (int)((n + epw - 1) / epw); }
 
-static inline int tern_level2(long long n)
+static inline int tern_level2(long long n, int epw)
 {
-    const int nw = tern_waves(n);
+    const int nw = tern_waves(n, epw);
     return nw > 2048 ? (nw + LEVEL_CHUNK - 1) / LEVEL_CHUNK : 0;
 }
+// workspace of a layer: sized for the kernels with the most wavefronts (the two-input gradient kernel)
 static inline size_t tern_seg_bytes(long long n)
 {
-    return ((((size_t)tern_waves(n) * 4 * sizeof(float)) + 255) & ~(size_t)255) + ((((size_t)tern_level2(n) * 4 * sizeof(float)) + 255) & ~(size_t)255);
+    const int epw = TERN_ELEMS_PER_WAVE_2IN;
+    return ((((size_t)tern_waves(n, epw) * 4 * sizeof(float)) + 255) & ~(size_t)255) + ((((size_t)tern_level2(n, epw) * 4 * sizeof(float)) + 255) & ~(size_t)255);
 }
 static size_t tern_ws_bytes(const aq_tern_seg *segs, int nseg)
 {
@@ -477,7 +485,7 @@ static int tern_validate(const char *who, const aq_tern_seg *segs, int nseg)
     return 0;
 }
 
-static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTab &tab)
+static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTab &tab, int epw = TERN_ELEMS_PER_WAVE)
 {
     tab.nseg = nseg;
     long long total = 0;
@@ -491,9 +499,9 @@ static int tern_table(const aq_tern_seg *segs, int nseg, void *workspace, TernTa
         d.w = s.W; d.dwt = s.dWt; d.mask = s.mask; d.codes = s.codes; d.packed = s.packed; d.wt = s.Wt; d.dw = s.dW;
         d.stats = s.stats; d.q = s.q; d.wp = s.Wp; d.wn = s.Wn; d.dwp = s.dWp; d.dwn = s.dWn;
         d.n = s.n;
-        d.nwave = tern_waves(s.n);
+        d.nwave = tern_waves(s.n, epw);
         d.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + off);
-        d.n2 = tern_level2(s.n);
+        d.n2 = tern_level2(s.n, epw);
         d.part2 = reinterpret_cast<float *>(static_cast<char *>(workspace) + off + ((((size_t)d.nwave * 4 * sizeof(float)) + 255) & ~(size_t)255));
         off += tern_seg_bytes(s.n);
         d.blk0 = (int)blocks;
@@ -550,15 +558,18 @@ int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int t
     const int blocks = tern_table(segs, nseg, workspace, tab);
     AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_fwd: too many elements for one launch");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(tern_absstat_kernel, dim3(blocks), dim3(256), 0, st, tab);
+    if (tab.nt) hipLaunchKernelGGL(tern_absstat_kernel<true>, dim3(blocks), dim3(256), 0, st, tab);
+    else hipLaunchKernelGGL(tern_absstat_kernel<false>, dim3(blocks), dim3(256), 0, st, tab);
     launch_levels<2, 1>(tab, st);
     hipLaunchKernelGGL(tern_delta_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab, factor, threshold_from_max ? 1 : 0);
     if (mode == AQ_TERN_TTQ) {
-        hipLaunchKernelGGL(tern_emit_kernel<true>, dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) hipLaunchKernelGGL((tern_emit_kernel<true, true>), dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL((tern_emit_kernel<true, false>), dim3(blocks), dim3(256), 0, st, tab);
         launch_levels<3, -1>(tab, st);
         hipLaunchKernelGGL(tern_codebook_kernel<true>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else {
-        hipLaunchKernelGGL(tern_emit_kernel<false>, dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) hipLaunchKernelGGL((tern_emit_kernel<false, true>), dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL((tern_emit_kernel<false, false>), dim3(blocks), dim3(256), 0, st, tab);
         launch_levels<3, -1>(tab, st);
         hipLaunchKernelGGL(tern_codebook_kernel<false>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
         if (decode) hipLaunchKernelGGL(tern_decode_kernel, dim3(blocks), dim3(256), 0, st, tab);
@@ -580,17 +591,20 @@ int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, si
     AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
                "aq_tern_bwd: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
     TernTab tab;
-    const int blocks = tern_table(segs, nseg, workspace, tab);
+    const int blocks = tern_table(segs, nseg, workspace, tab, mode == AQ_TERN_TTQ ? TERN_ELEMS_PER_WAVE_2IN : TERN_ELEMS_PER_WAVE);
     AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_bwd: too many elements for one launch");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == AQ_TERN_TTQ) {
-        hipLaunchKernelGGL(tern_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<1, true>), dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL((tern_bwd_kernel<1, false>), dim3(blocks), dim3(256), 0, st, tab);
         launch_levels<2, -1>(tab, st);
         hipLaunchKernelGGL(tern_scale_grad_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else if (mode == AQ_TERN_INQ) {
-        hipLaunchKernelGGL(tern_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<2, true>), dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL((tern_bwd_kernel<2, false>), dim3(blocks), dim3(256), 0, st, tab);
     } else {
-        hipLaunchKernelGGL(tern_bwd_kernel<0>, dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<0, true>), dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL((tern_bwd_kernel<0, false>), dim3(blocks), dim3(256), 0, st, tab);
     }
     return check_launch("aq_tern_bwd");
 }
