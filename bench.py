@@ -84,7 +84,7 @@ def kernel_rooflines(quick):
     a1 = rows * (4 * L + 4) / t1 / 1e9
     # traffic: not measured in this run; the committed PMC result for the same launch (FETCH_SIZE x 2 + WRITE_SIZE)
     src = "profiles/r02_roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
-    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false, false> (fast arithmetic, streaming loads)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false, false, 4> (fast arithmetic, streaming loads, 32 rows per wavefront)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
@@ -108,8 +108,9 @@ def kernel_rooflines(quick):
     p31 = p.view(-1)[:rows * L31].view(rows, L31)
     q31 = torch.cat([q[:15], torch.zeros(1, device=dev), q[17:]]).contiguous()
     dp31 = [dp[0].view(-1)[:rows * L31].view(rows, L31)]
-    t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 10)
-    t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 10)
+    # (twenty warm-up launches: this instruction-heavier kernel runs 10-25 % slower right after a pause)
+    t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 20, warm=20)
+    t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 20, warm=20)
     for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 3, false, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 3, false, false> (L = 31)", t31b, 8 * L31 + 4)):
         aa = rows * bpr / tt / 1e9
         more.append({"bound": "hbm", "kernel": nm, "achieved": round(aa, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(aa / HBM_PEAK_GBS, 4),
@@ -180,13 +181,13 @@ def kernel_rooflines(quick):
     w = torch.randn(n, device=dev) * 0.05
     gw = torch.randn(n, device=dev)
     tq = event_time(lambda: ops.tern_forward([w], "twn", decoded=False), 10)
-    more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel + tern_emit_kernel<false> + second stages (threshold 0.7*mean|w|, 1-byte codes)",
+    more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel<true> + tern_emit_kernel<false, true> + second stages (threshold 0.7*mean|w|, 1-byte codes)",
                  "achieved": round(n * 9 / tq / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 9 / tq / 1e9 / HBM_PEAK_GBS, 4),
                  "traffic": traffic_tern if not quick else None, "bytes_per_weight": 9, "weights_per_call": n, "avg_call_ms": round(tq * 1e3, 4), "parity": "unpinned (no reference implementation)"})
     Wp, Wn = [torch.full((1,), 0.1, device=dev)], [torch.full((1,), 0.08, device=dev)]
     st = ops.tern_forward([w], "ttq", Wp=Wp, Wn=Wn)[0]["stats"]
     tb = event_time(lambda: ops.tern_backward([w], [gw], "ttq", stats=[st], Wp=Wp, Wn=Wn), 10)
-    more.append({"bound": "hbm", "kernel": "aq::tern_bwd_kernel<1> (TTQ straight-through + scale gradients)", "achieved": round(n * 12 / tb / 1e9, 1),
+    more.append({"bound": "hbm", "kernel": "aq::tern_bwd_kernel<1, true> (TTQ straight-through + scale gradients)", "achieved": round(n * 12 / tb / 1e9, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 12 / tb / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_weight": 12, "weights_per_call": n,
                  "avg_call_ms": round(tb * 1e3, 4), "parity": "unpinned (no reference implementation)"})
     del w, gw

@@ -71,7 +71,8 @@ int aq_synth_fwd(const aq_seg *segs, int nseg, float beta, unsigned flags, void 
  * library (a device array of AQ_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
  * process ends) and the call allocates nothing, on the device or through any library.  Layers whose
  * aq_synth_workspace_bytes(segs, nseg, 0) exceeds AQ_STATIC_SCRATCH_BYTES are rejected with -E2BIG (one layer
- * of up to ~33 M weights fits; calls without any sumsq output need no workspace at all).  All calls on one GPU
+ * of up to ~33 M weights fits, ~16 M weights of 32 levels in a call of more than 128 MiB, which may run twice as
+ * many wavefronts; calls without any sumsq output need no workspace at all).  All calls on one GPU
  * share that workspace: calls that overlap in time on one GPU (different streams or threads) race on it and
  * give wrong sumsq; nothing in it needs clearing between calls (every partial read is written first). */
 #define AQ_STATIC_SCRATCH_BYTES (2u << 20)

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -107,26 +108,26 @@ __device__ __forceinline__ void store_elems(float *__restrict__ p, long long r, 
 // the lane at the ragged row end, whose access runs up to 3 elements into the rows that follow; those elements are zeroed after
 // the load.  That is one memory instruction per row instead of four (a vector access for the full lanes plus three predicated
 // scalars for the ragged one), and no address clamping.
-template <int G, int MEM>
-__device__ __forceinline__ void load_rows8(const float *__restrict__ p, long long R0, long long rows, int L, int j, int gq, bool fast, float (&v)[8][4])
+template <int G, int MEM, int NU = 8>
+__device__ __forceinline__ void load_rows8(const float *__restrict__ p, long long R0, long long rows, int L, int j, int gq, bool fast, float (&v)[NU][4])
 {
     constexpr int RPP = 64 / G;
     if (!mem_vec(MEM) && fast) {
-        f4 t[8];
+        f4 t[NU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int u = 0; u < NU; ++u) t[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if (4 * j < L) {
             const float *a = p + (R0 + gq) * (long long)L + 4 * j;
             const long long step = (long long)RPP * L;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const f4_a4 *src = reinterpret_cast<const f4_a4 *>(a + u * step);
                 t[u] = mem_nt(MEM) ? __builtin_nontemporal_load(src) : *src;
             }
         }
         const bool k1 = 4 * j + 1 < L, k2 = 4 * j + 2 < L, k3 = 4 * j + 3 < L;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             v[u][0] = t[u].x;
             v[u][1] = k1 ? t[u].y : 0.0f;
             v[u][2] = k2 ? t[u].z : 0.0f;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void load_rows8(const float *__restrict__ p, long lon
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const long long r = R0 + u * RPP + gq;
             load_elems<G, MEM>(p, r < rows ? r : rows - 1, L, j, v[u]);
         }
@@ -209,10 +210,17 @@ __device__ __forceinline__ float key_float(uint32_t k)
 // strictly smaller after exp as well.  A row with a second element inside that distance (about one row in
 // 10^4 for uniform p), a non-finite or zero norm, or beta <= 0 goes through the exact sequence, so the codes are
 // those of the exact kernel bit for bit, at the cost of one compare-and-count per element instead of an exp.
-template <int G, int MEM, bool HARD, bool EXACT, bool CODES_ONLY = false>
+// NU: rows per lane group and batch.  8 = 64 rows per wavefront iteration.  4 (G = 8 only) = 32 rows: on tensors
+// beyond the last-level cache twice as many, half as long wavefronts run the soft fast-arithmetic pass 3-4 % faster
+// (6.33 against 6.15 TB/s at 250 M coefficients; lanes j < 4 of a group then own the rows).  Measured slower for the
+// instruction-heavier forms (codes-only 5.2 against 5.6 TB/s, exact 4.3 against 4.7) and for ragged rows (5.95 against
+// 6.24), which stay at 64 rows.
+template <int G, int MEM, bool HARD, bool EXACT, bool CODES_ONLY = false, int NU = 8>
 __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const float beta)
 {
+    static_assert(NU == 8 || (NU == 4 && G == 8), "half batches exist for 8 lanes per row only");
     constexpr int RPP = 64 / G;
+    constexpr int ROWS = 8 * NU;  // rows per wavefront iteration
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront-uniform: row ranges stay in scalar registers
     const int j = lane % G, gq = lane / G;
     const int si = find_segment(tab);
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
     const int L = tab.s[si].L;
 
     const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
-    const long long row_begin = wt * tab.K * ROWS_IT;
+    const long long row_begin = wt * tab.K * ROWS;
     if (row_begin >= rows) return;
 
     float q4[4];
@@ -239,19 +247,19 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 
     float acc = 0.0f;
     for (int it = 0; it < tab.K; ++it) {
-        const long long row0 = row_begin + (long long)it * ROWS_IT;
+        const long long row0 = row_begin + (long long)it * ROWS;
         if (row0 >= rows) break;
-        const bool fast_rows = row0 + ROWS_IT + 4 <= rows;
+        const bool fast_rows = row0 + ROWS + 4 <= rows;
         float myW = 0.0f;
         uint32_t myIdx = 0;
         static_for<G / 8>([&](auto UB) {
             constexpr int ub = 8 * decltype(UB)::value;
-            float v[8][4];
-            load_rows8<G, MEM>(p, row0 + ub * RPP, rows, L, j, gq, fast_rows, v);
+            float v[NU][4];
+            load_rows8<G, MEM, NU>(p, row0 + ub * RPP, rows, L, j, gq, fast_rows, v);
             // squared norms of the 8 rows; lane j == ub+u keeps row u's and inverts it once
             float my_ss = 1.0f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const float ss = group_sum<G>(chain_sq(v[u]));
                 my_ss = (j == ub + u) ? ss : my_ss;
             }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                 // distance in p that corresponds to the safety distance in x: (2e-6 + 1e-6 * beta) / (beta * rn)
                 const float my_thr = (2e-6f / beta + 1e-6f) * __builtin_sqrtf(my_ss);
                 bool my_bad = !(my_ss > 0.0f && my_ss < __builtin_inff()) || !(beta > 0.0f);
-                static_for<8>([&](auto U) {
+                static_for<NU>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const float thr = group_bcast<G, ub + u>(my_thr);
                     float pv[4];
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                 });
                 slow = __builtin_amdgcn_ballot_w64(my_bad) != 0;
             }
-            if (slow) static_for<8>([&](auto U) {
+            if (slow) static_for<NU>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const float rn = group_bcast<G, ub + u>(my_rn);
                 float e[4];
@@ -320,13 +328,13 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
                 my_bi = mine ? bi : my_bi;
             });
             const float w = my_num * (1.0f / my_den);
-            const bool owner = (j >= ub) && (j < ub + 8);
+            const bool owner = (j >= ub) && (j < ub + NU);
             myW = owner ? w : myW;
             if constexpr (HARD) myIdx = owner ? ((my_den == my_den) ? my_bi : 0u) : myIdx;  // (fast path: my_den stays 1)
         });
         // lane (gq, j) now holds row j*RPP + gq of this iteration: one coalesced store each
         const long long rr = row0 + (long long)j * RPP + gq;
-        if (rr < rows) {
+        if (rr < rows && (NU == 8 || j < NU)) {
             if (W) W[rr] = myW;
             if constexpr (HARD) {
                 if (idx) idx[rr] = (uint8_t)myIdx;
@@ -348,9 +356,11 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 // with step_size = lr/(1-beta1^t), rbc2 = 1/sqrt(1-beta2^t) prepared per layer by adam_prep_kernel.
 // This removes the dp_c round trip through memory: 6 tensor passes (p, m, v read and written) instead
 // of 2 (K2) + 7 (separate Adam).
-template <int G, int MEM, bool EXACT, bool ADAM>
+template <int G, int MEM, bool EXACT, bool ADAM, int NU = 8>  // NU: as in synth_fwd_kernel
 __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd, const AdamArgs ad)
 {
+    static_assert(NU == 8 || (NU == 4 && G == 8), "half batches exist for 8 lanes per row only");
+    constexpr int ROWS = 8 * NU;  // rows per wavefront iteration
     constexpr int RPP = 64 / G;
     constexpr int LP = 4 * G;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront-uniform: row ranges stay in scalar registers
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
     constexpr bool rag_stream = mem_nt(MEM);
 
     const long long wt = (long long)((int)blockIdx.x - tab.s[si].blk0) * WAVES + wave;
-    const long long row_begin = wt * tab.K * ROWS_IT;
+    const long long row_begin = wt * tab.K * ROWS;
     if (row_begin >= rows) return;
 
     float q4[4];
@@ -390,46 +400,46 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
 
     float accq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; it < tab.K; ++it) {
-        const long long row0 = row_begin + (long long)it * ROWS_IT;
+        const long long row0 = row_begin + (long long)it * ROWS;
         if (row0 >= rows) break;
-        const bool fast_rows = row0 + ROWS_IT + 4 <= rows;
+        const bool fast_rows = row0 + ROWS + 4 <= rows;
         // FR = true: ragged rows leaving through LDS, and every row of the batch present (all but the last wavefronts of a
         // layer): no row clamping, no per-row bounds, one 16-byte access per lane and row in both directions.
         auto batch = [&](auto FR) {
             constexpr bool FASTRAG = decltype(FR)::value;
             static_for<G / 8>([&](auto UB) {
                 constexpr int ub = 8 * decltype(UB)::value;
-                float v[8][4];
-                float gw[8];
-                float m1[8][4], m2[8][4];  // (unused and removed by the compiler without ADAM)
+                float v[NU][4];
+                float gw[NU];
+                float m1[NU][4], m2[NU][4];  // (unused and removed by the compiler without ADAM)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) gw[u] = 0.0f;
+                for (int u = 0; u < NU; ++u) gw[u] = 0.0f;
                 if (dW) {
                     if (FASTRAG || fast_rows) {
                         const float *g0 = dW + (row0 + ub * RPP + gq);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gw[u] = g0[u * RPP];
+                        for (int u = 0; u < NU; ++u) gw[u] = g0[u * RPP];
                     } else {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < NU; ++u) {
                             const long long r = row0 + (ub + u) * RPP + gq;
                             gw[u] = dW[r < rows ? r : rows - 1];
                         }
                     }
                 }
-                load_rows8<G, MEM>(p, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, v);
+                load_rows8<G, MEM, NU>(p, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, v);
                 if constexpr (ADAM) {
-                    load_rows8<G, MEM>(am, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m1);
-                    load_rows8<G, MEM>(av, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m2);
+                    load_rows8<G, MEM, NU>(am, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m1);
+                    load_rows8<G, MEM, NU>(av, row0 + ub * RPP, rows, L, j, gq, FASTRAG || fast_rows, m2);
                 }
                 float my_ss = 1.0f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     const float ss = group_sum<G>(chain_sq(v[u]));
                     my_ss = (j == ub + u) ? ss : my_ss;
                 }
                 const float my_rn = inv_norm(my_ss);
-                static_for<8>([&](auto U) {
+                static_for<NU>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const long long r = row0 + (ub + u) * RPP + gq;
                     const float rn = group_bcast<G, ub + u>(my_rn);
@@ -604,7 +614,19 @@ static inline int choose_K(long long total_rows)
     return 1;
 }
 
-static inline long long wave_tiles(long long rows, int K) { return (rows + (long long)K * ROWS_IT - 1) / ((long long)K * ROWS_IT); }
+static inline long long wave_tiles(long long rows, int K, int rows_it = ROWS_IT) { return (rows + (long long)K * rows_it - 1) / ((long long)K * rows_it); }
+
+// streaming cache policy when the tensors cannot stay in the 256 MiB last-level cache anyway
+// (what counts is the traffic of the call: with Adam, p, m and v are each read and written)
+static inline bool call_streams(const aq_seg *segs, int nseg, bool adam)
+{
+    long long total_bytes = 0;
+    for (int i = 0; i < nseg; ++i) total_bytes += segs[i].rows * (long long)segs[i].L * 4;
+    return total_bytes * (adam ? 6 : 1) > (128LL << 20);
+}
+// fewest rows per wavefront iteration a layer can get (sizes the workspace): the soft fast-arithmetic forward pass runs
+// 32-row wavefronts on streamed, 16-byte-aligned layers of 32 levels (run() decides with the flags of the call)
+static inline int rows_per_wave(bool bwd, int L, bool streams) { (void)bwd; return (streams && L == 32) ? 32 : ROWS_IT; }
 
 struct Plan {
     int K;
@@ -641,13 +663,14 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
     long long total = 0;
     for (int i = 0; i < nseg; ++i) total += segs[i].rows;
     pl.K = choose_K(total);
+    const bool streams = call_streams(segs, nseg, bwd);  // (backward: the traffic multiplier of the Adam form, an upper bound)
     size_t off = 0;
     for (int i = 0; i < nseg; ++i) {
         pl.off[i] = off;
         const bool need = bwd ? segs[i].dq != nullptr : segs[i].sumsq != nullptr;
         if (need && segs[i].rows > 0) {
             const size_t width = bwd ? 4 * lanes_for(segs[i].L) : 1;
-            const long long nw = wave_tiles(segs[i].rows, pl.K);
+            const long long nw = wave_tiles(segs[i].rows, pl.K, rows_per_wave(bwd, segs[i].L, streams));
             size_t n = (size_t)nw * width * sizeof(float);
             off += (n + 255) & ~(size_t)255;
             pl.tmp[i] = off;
@@ -660,15 +683,22 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
 
 template <bool BWD>
 static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, const AdamArgs *adam,
-                         hipStream_t st, bool codes_only = false)
+                         hipStream_t st, bool codes_only = false, bool half = false)
 {
     const AdamArgs ad = adam ? *adam : AdamArgs{};
 #define AQ_LAUNCH(GG, MM)                                                                                             \
-    if (BWD) {                                                                                                        \
+    if (BWD && half && GG == 8 && MM == 2 && !exact) {                                                              \
+        constexpr int NH = (GG == 8 && MM == 2) ? 4 : 8;                                                              \
+        if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+    } else if (BWD) {                                                                                                 \
         if (adam && exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
         else if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
         else if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
         else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+    } else if (half && GG == 8 && MM == 2 && !hard && !exact) {                                                      \
+        constexpr int NH = (GG == 8 && MM == 2) ? 4 : 8;                                                              \
+        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta); \
     } else if (hard && codes_only)                                                                                    \
         hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); \
     else if (hard)                                                                                                    \
@@ -723,11 +753,22 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
         ad_dev.omb1 = (float)(1.0 - adam->b1); ad_dev.b2 = (float)adam->b2; ad_dev.omb2 = (float)(1.0 - adam->b2); ad_dev.eps = (float)adam->eps;
     }
 
-    // streaming cache policy when the tensors cannot stay in the 256 MiB last-level cache anyway
-    long long total_bytes = 0;
-    for (int i = 0; i < nseg; ++i) total_bytes += segs[i].rows * (long long)segs[i].L * 4;
-    // (what counts is the traffic of the call: with Adam, p, m and v are each read and written)
-    const bool stream_policy = total_bytes * (adam ? 6 : 1) > (128LL << 20);
+    const bool stream_policy = call_streams(segs, nseg, adam != nullptr);
+    bool any_hard = false;
+    for (int i = 0; i < nseg; ++i) any_hard = any_hard || segs[i].idx != nullptr || segs[i].W_hard != nullptr;
+    // 32-row wavefronts for the aligned 32-level layers of large calls in fast arithmetic: forward without codes +2-4 %,
+    // gradient +3-5 %, gradient with Adam +4-12 % on 50 M .. 1 B coefficients.  (A training step's 19 layers, 0.27 M rows,
+    // measured no faster and keep 64 rows; so do ragged rows: 5.24 against 5.41 TB/s in the gradient at L = 31.)
+    int half_mask = 7;  // 1 forward, 2 gradient, 4 gradient with Adam
+#ifdef AQ_EXPERIMENT
+    if (const char *e = getenv("AQ_SYNTH_HALF")) half_mask = atoi(e);
+#endif
+    long long call_rows = 0;
+    for (int i = 0; i < nseg; ++i) call_rows += segs[i].rows;
+    const bool half_call = stream_policy && !exact && call_rows >= (1LL << 19) &&
+                           (BWD ? (half_mask & (adam ? 4 : 2)) != 0 : (!any_hard && (half_mask & 1)));
+    static thread_local unsigned char seg_rows_it[1 << 12];
+    for (int i = 0; i < nseg; ++i) seg_rows_it[i] = ROWS_IT;
 
     // main launches: one per (lanes-per-row, memory access) class, at most MAX_SEGS segments each
     for (int G = 8; G <= 32; G <<= 1)
@@ -740,7 +781,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             auto flush = [&]() {
                 if (tab.nseg)
                     launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : (stream_policy ? 3 : 0), hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st,
-                                      hard && !wants_w);
+                                      hard && !wants_w, half_call && vec);
                 tab.nseg = 0;
                 nblocks = 0;
                 hard = wants_w = false;
@@ -767,7 +808,8 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
                 }
                 hard = hard || s.idx != nullptr || s.W_hard != nullptr;
                 wants_w = wants_w || s.W != nullptr || d.part != nullptr;
-                const long long nb = (wave_tiles(s.rows, pl.K) + WAVES - 1) / WAVES;
+                if (half_call && G == 8 && v) seg_rows_it[i] = 32;
+                const long long nb = (wave_tiles(s.rows, pl.K, seg_rows_it[i]) + WAVES - 1) / WAVES;
                 AQ_REQUIRE(nb + nblocks < (1LL << 31), -E2BIG, "segment %d: too many rows for one launch", i);
                 nblocks += (int)nb;
                 if (++tab.nseg == MAX_SEGS) flush();
@@ -785,7 +827,7 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
         float *out = BWD ? s.dq : s.sumsq;
         cur_n[i] = -1;
         if (!out) continue;
-        cur_n[i] = s.rows ? wave_tiles(s.rows, pl.K) : 0;
+        cur_n[i] = s.rows ? wave_tiles(s.rows, pl.K, seg_rows_it[i]) : 0;
         cur_src[i] = reinterpret_cast<const float *>(static_cast<const char *>(workspace) + pl.off[i]);
         more = true;
     }
