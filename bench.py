@@ -66,8 +66,8 @@ def kernel_rooflines(quick):
     dW = torch.randn(rows, device=dev, generator=g)
     W = [torch.empty(rows, device=dev)]
     dp = [torch.empty_like(p)]
-    t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20)
-    t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 10)
+    t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20, warm=10)
+    t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 20, warm=10)
     # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc on the same
     # 250 M-element tensor, see profiles/r02_roofline_traffic.json); only valid for the full-size tensor
     traffic = traffic2 = traffic3 = traffic_codes = traffic_tern = None
@@ -92,13 +92,13 @@ def kernel_rooflines(quick):
              "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": traffic2, "bytes_per_row": 8 * L + 4, "rows_per_launch": rows,
              "avg_launch_ms": round(t2 * 1e3, 4)}]
     # the code-emitting forward (hard mode, what an evaluation pass runs: 1-byte code and q[code] per row)
-    th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=False, codes=True), 10)
+    th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=False, codes=True), 20, warm=10)
     ah = rows * (4 * L + 5) / th / 1e9
     more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, true> (codes + q[code]; arg-max of p, exact sequence on near ties)",
                  "achieved": round(ah, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "traffic": traffic_codes,
                  "bytes_per_row": 4 * L + 5, "rows_per_launch": rows, "avg_launch_ms": round(th * 1e3, 4)})
     # soft W, codes and q[code] together in exact arithmetic (bit-reproducible against the CPU restatement)
-    th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, codes=True), 10)
+    th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, codes=True), 20, warm=10)
     ah = rows * (4 * L + 9) / th / 1e9
     more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, false> (W + codes + q[code], exact arithmetic)", "achieved": round(ah, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "bytes_per_row": 4 * L + 9, "rows_per_launch": rows,
@@ -194,7 +194,7 @@ def kernel_rooflines(quick):
     torch.cuda.empty_cache()
     B18 = 32
     for (cin, cout, ks, s, pd, H) in [(3, 64, 7, 2, 3, 224), (64, 64, 3, 1, 1, 56), (128, 128, 3, 1, 1, 28), (256, 256, 3, 1, 1, 14), (512, 512, 3, 1, 1, 7),
-                                      (128, 256, 3, 2, 1, 28)]:
+                                      (128, 256, 3, 2, 1, 28), (64, 128, 1, 2, 0, 56)]:
         x = torch.randn(B18, cin, H, H, device=dev)
         Wc = torch.randn(cout, cin, ks, ks, device=dev) * 0.05
         y = ops.conv_forward(x, Wc, s, pad=pd)

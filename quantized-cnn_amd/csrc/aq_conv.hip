@@ -1814,6 +1814,10 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
         if (dry) return 0;
         AQ_REQUIRE(!a.bn_on && !a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no fused normalisation / statistics epilogue for this kernel size", who);
         bool taken = false;
+        if (a.ks == 1 && MODE != MODE_FWD_CODES) {  // 1x1: a plain GEMM, nothing to stage
+            const int rc1 = MODE == MODE_DGRAD ? aq_c1_launch_dgrad(a, N, st, who, &taken) : aq_c1_launch_fwd(a, N, st, who, &taken);
+            if (taken) return rc1;
+        }
         const int rc = launch_c3<MODE>(a, N, st, who, &taken);
         if (taken) return rc;
         return launch_chunked<MODE>(a, N, st, who);

@@ -117,6 +117,13 @@ struct WgC16Args {
 int aq_c16_launch_fwd(aq::ConvArgs a, int N, hipStream_t st, const char *who, bool *taken);
 int aq_c16_launch_dgrad(aq::ConvArgs a, int N, hipStream_t st, const char *who, bool *taken);
 
+// ---- aq_conv_1x1.hip ------------------------------------------------------------------------------------------
+// forward / input gradient of 1x1 layers without padding (stride 1 | 2) whose channel counts are multiples of 16;
+// *taken = false: not one of its shapes, nothing launched
+int aq_c1_launch_fwd(const aq::ConvArgs &a, int N, hipStream_t st, const char *who, bool *taken);
+int aq_c1_launch_dgrad(const aq::ConvArgs &a, int N, hipStream_t st, const char *who, bool *taken);
+
+// ---- aq_conv_c16.hip (continued) ------------------------------------------------------------------------------
 // weight gradient of 3x3 (input channels a multiple of 16) and 1x1 (a multiple of 64) layers with output channels a
 // multiple of 16: plan (use = false: not one of its shapes) and launch for a group of layers
 struct WgC16Plan {

@@ -109,3 +109,41 @@ def test_adjoint_identity_at_resnet18_sizes():
     assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale
     yt = torch.nn.functional.conv2d(x, W, padding=1)
     assert (y - yt).abs().max().item() <= 1e-4 * yt.abs().max().item()  # (stock fp32 conv may use other arithmetic)
+
+
+ONE_BY_ONE = [  # cin, cout, stride, H, W, N: the GEMM kernel of the 1x1 layers (channel counts multiples of 16)
+    (64, 128, 2, 56, 56, 2),     # ResNet-18 layer2.0 projection
+    (128, 256, 2, 28, 28, 3),
+    (256, 512, 2, 14, 14, 2),
+    (64, 64, 1, 9, 9, 2),        # stride 1
+    (48, 32, 2, 11, 13, 3),      # odd sizes: the last cells of the input gradient own a trailing row / column; 2 channel blocks per wavefront
+    (32, 16, 2, 7, 6, 1),        # one channel block per wavefront; fewer than 16 pixels in the last wavefront
+    (16, 80, 1, 5, 3, 5),
+    (80, 48, 2, 2, 2, 70),       # one output pixel per image
+]
+
+
+@pytest.mark.parametrize("shape", ONE_BY_ONE, ids=lambda s: "x".join(map(str, s)))
+def test_one_by_one_gemm_forward_and_dgrad_vs_oracle(shape):
+    """1x1 / padding 0: forward (with and without the added tensor), input gradient (plain: every element of dx is
+    written, the positions no output reads with zeros, into a buffer full of NaN; and with the added tensor)."""
+    cin, cout, stride, H, Wd, N = shape
+    rs = np.random.RandomState(11 + sum(shape))
+    x = rs.standard_normal((N, cin, H, Wd)).astype(np.float32)
+    W = (rs.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    y_ref = O.conv_fwd(x, W, stride, 0)
+    xd, Wdv = cu(x), cu(W)
+    near(ops.conv_forward(xd, Wdv, stride, pad=0).cpu().numpy(), y_ref, "y")
+    res = rs.standard_normal(y_ref.shape).astype(np.float32)
+    near(ops.conv_forward(xd, Wdv, stride, res=cu(res), pad=0).cpu().numpy(), y_ref + res, "y + res")
+    dy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv_dgrad(dy, W, x.shape, stride, 0)
+    dx = ops.conv_dgrad(cu(dy), Wdv, x.shape, stride, pad=0).cpu().numpy()
+    assert np.isfinite(dx).all()
+    near(dx, dx_ref, "dx")
+    if stride == 2:  # exact zeros where no output reads x
+        mask = np.ones((H, Wd), bool)
+        mask[::2, ::2] = False
+        assert np.all(dx[:, :, mask] == 0.0)
+    xres = rs.standard_normal(x.shape).astype(np.float32)
+    near(ops.conv_dgrad(cu(dy), Wdv, x.shape, stride, res=cu(xres), pad=0).cpu().numpy(), dx_ref + xres, "dx + res")
