@@ -218,6 +218,38 @@ def kernel_rooflines(quick):
     return roof, more
 
 
+def ternary_step(steps=100, warmup=20):
+    """BASELINE configs[1] read literally: the ResNet-20 graph with TTQ convolutions (learned Wp / Wn; the papers'
+    quantiser, no reference implementation: parity unpinned), batch 128, same step shape as the headline workload
+    (forward, cross entropy + l2, backward, Adam), replayed as one HIP graph."""
+    import quantized_cnn_amd.ternary as ternary
+    from quantized_cnn_amd.train import TrainStep, make_optimizers
+    out = {}
+    for mode in ("ttq", "twn"):
+        c = cfg()
+        c.mode_q = mode
+        torch.manual_seed(0)
+        model = ternary.ResNet(c, 3).cuda().train()
+        step = TrainStep(model, c, ternary, use_graph=True)
+        step.opts = make_optimizers(model, c, capturable=True, fused=True)  # torch's fused Adam kernels inside the graph
+        g = torch.Generator(device="cuda").manual_seed(1000)
+        x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
+        y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
+        for _ in range(warmup):
+            step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {"value": round(BATCH / dt, 1), "unit": "img/s", "ms_per_step": round(dt * 1e3, 4), "final_loss": round(float(loss), 5)}
+    out["workload"] = ("ResNet-20 with ternary convolutions (quantized_cnn_amd.ternary.ResNet: TTQ learned Wp / Wn, TWN), batch %d, synthetic "
+                       "CIFAR-10, TrainStep(use_graph=True) with torch's fused Adam: fwd + CE + l2 + bwd + Adam in one HIP graph" % BATCH)
+    out["parity"] = "unpinned (no reference implementation)"
+    return out
+
+
 def cpu_baseline(quick):
     """CPU port of the same step (oracle/torch_port.py, pinned to the reference by tests) on the host."""
     from oracle import torch_port as TP
@@ -364,6 +396,7 @@ def main():
             roof, more = kernel_rooflines(args.quick)
             out["roofline"] = roof
             out["roofline_more"] = more
+            out["ternary_resnet20"] = ternary_step(20 if args.quick else 100, 5 if args.quick else 20)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.quick)
         print(json.dumps(out), flush=True)

@@ -80,6 +80,7 @@ class ResNet18(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._synthesize_all()
+        ternary.quantize_all([m for m in self.modules() if isinstance(m, ternary._TernBase)])
         c0 = self.conv0
         out = layers.conv3x3(x, c0.weight, 2, None, pad=3)
         out = self.pool0(layers.bn_relu(self.bn0, out))

@@ -22,6 +22,17 @@ from .layers import model_loss  # noqa: F401  (l2 on every "weight" parameter, a
 beta = 1  # unused by these layers; present so that train.TrainStep can treat this module like a variant module
 
 
+def _conv_quantized(x, q, layer):
+    """Forward convolution on a quantised weight: from the 1-byte codes + codebook where a kernel decodes them while it
+    stages the weight tile into LDS (the ResNet-20 shapes, small channel counts, 5x5 / 7x7), from the decoded weights
+    on the many-channel 3x3 / 1x1 kernels, whose weight fragments go from memory straight to registers."""
+    cout, cin = q["codes"].shape[0], q["codes"].shape[1]
+    many = cin % 16 == 0 and ((layer.ksize == 3 and cout >= 48) or (layer.ksize == 1 and cout % 16 == 0 and layer.padding == 0))
+    if many:
+        return ops.conv_forward(x, q["Wt"], layer.stride, pad=layer.padding)
+    return ops.conv_forward_codes(x, q["codes"], q["q"], layer.stride, layer.padding)
+
+
 class _TernConv(torch.autograd.Function):
     """y = conv(x, w~): forward from codes + codebook, backward through the decoded w~ and the quantiser's
     straight-through rule.  q: pre-computed dict of ops.tern_forward for this weight (or None)."""
@@ -33,7 +44,7 @@ class _TernConv(torch.autograd.Function):
             q = layer.quantize()
         ctx.layer, ctx.q = layer, q
         ctx.save_for_backward(x, w, Wp, Wn)
-        return ops.conv_forward_codes(x, q["codes"], q["q"], layer.stride, layer.padding)
+        return _conv_quantized(x, q, layer)
 
     @staticmethod
     def backward(ctx, dy):
@@ -73,6 +84,74 @@ class _TernLinear(torch.autograd.Function):
         return dx, dW[0], db, None, None, None, None
 
 
+class _QuantizeAll(torch.autograd.Function):
+    """The quantised weights of ALL ternary layers of a model as one autograd node: forward = one ops.tern_forward
+    call (five launches for every layer together), backward = one ops.tern_backward call once the weight gradients
+    of every layer have arrived (a launch and its second stage instead of one pair per layer).
+    apply(mode_q, factor, threshold_from_max, n, sink, w_0 .. w_{n-1} [, Wp_0 .. Wp_{n-1}, Wn_0 .. Wn_{n-1}])
+    -> (Wt_0, .., Wt_{n-1}); sink (a list) receives the per-layer dicts of ops.tern_forward."""
+
+    @staticmethod
+    def forward(ctx, mode_q, factor, threshold_from_max, n, sink, *ts):
+        ws = [t.detach() for t in ts[:n]]
+        ctx.mode_q, ctx.n = mode_q, n
+        if mode_q == "ttq":
+            Wp, Wn = [t.detach() for t in ts[n:2 * n]], [t.detach() for t in ts[2 * n:3 * n]]
+            qs = ops.tern_forward(ws, "ttq", factor, threshold_from_max, Wp, Wn)
+        else:
+            qs = ops.tern_forward(ws, "twn", factor, threshold_from_max)
+        sink.extend(qs)
+        ctx.stats = [q["stats"] for q in qs]
+        ctx.save_for_backward(*ts)
+        return tuple(q["Wt"] for q in qs)
+
+    @staticmethod
+    def backward(ctx, *dWt):
+        ts, n = ctx.saved_tensors, ctx.n
+        ws = list(ts[:n])
+        g = [d.contiguous() for d in dWt]
+        if ctx.mode_q == "ttq":
+            Wp, Wn = list(ts[n:2 * n]), list(ts[2 * n:3 * n])
+            dW, dp, dn = ops.tern_backward(ws, g, "ttq", stats=ctx.stats, Wp=Wp, Wn=Wn)
+            return (None,) * 5 + tuple(dW) + tuple(d.reshape(p.shape) for d, p in zip(dp, Wp)) + tuple(d.reshape(p.shape) for d, p in zip(dn, Wn))
+        dW, _, _ = ops.tern_backward(ws, g, "twn")
+        return (None,) * 5 + tuple(dW)
+
+
+class _ConvFromQuantized(torch.autograd.Function):
+    """y = conv(x, w~) for a w~ that _QuantizeAll produced: forward from its codes + codebook, backward through the
+    decoded w~; the weight gradient leaves as the gradient of w~ (the quantiser's rule is applied by _QuantizeAll)."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, layer, q):
+        x = x.contiguous()
+        ctx.layer = layer
+        ctx.save_for_backward(x, Wt)
+        return _conv_quantized(x, q, layer)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wt = ctx.saved_tensors
+        L = ctx.layer
+        dy = dy.contiguous()
+        dx = ops.conv_dgrad(dy, Wt, x.shape, L.stride, pad=L.padding) if ctx.needs_input_grad[0] else None
+        return dx, ops.conv_wgrad(x, dy, L.stride, ks=L.ksize, pad=L.padding), None, None
+
+
+class _LinearFromQuantized(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wt, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, Wt)
+        return ops.linear_forward(x, Wt, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wt = ctx.saved_tensors
+        dx, dWt, db = ops.linear_backward(x, Wt, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return dx, dWt, db
+
+
 class _TernBase(nn.Module):
     def _setup_quantizer(self, mode_q, factor, threshold_from_max):
         if mode_q not in ("twn", "ttq"):
@@ -95,7 +174,7 @@ class _TernBase(nn.Module):
         """-> dict of ops.tern_forward for this layer's weight (codes, Wt, stats, q[, packed])."""
         if self._shared is not None and not packed:
             q, self._shared = self._shared, None
-            return q
+            return q[0] if isinstance(q, tuple) else q
         w = self.weight.detach()
         if self.mode_q == "ttq":
             return ops.tern_forward([w], "ttq", self.factor, self.threshold_from_max, [self.Wp.detach()], [self.Wn.detach()], packed=packed)[0]
@@ -121,7 +200,11 @@ class TernaryConv2d(_TernBase):
                 z = layers.bn_relu(bn, x)
         else:
             z = x
-        y = _TernConv.apply(z, self.weight, self.Wp, self.Wn, self, None)
+        if isinstance(self._shared, tuple) and torch.is_grad_enabled():  # quantised with the model's other layers (ResNet._quantize_all)
+            (q, Wt), self._shared = self._shared, None
+            y = _ConvFromQuantized.apply(z, Wt, self, q)
+        else:
+            y = _TernConv.apply(z, self.weight, self.Wp, self.Wn, self, None)
         if res is not None:
             y = y + res
         if isinstance(split, tuple):
@@ -139,6 +222,9 @@ class TernaryLinear(_TernBase):
         self._setup_quantizer(mode_q, factor, threshold_from_max)
 
     def forward(self, x):
+        if isinstance(self._shared, tuple) and torch.is_grad_enabled():
+            (q, Wt), self._shared = self._shared, None
+            return _LinearFromQuantized.apply(x, Wt, self.bias)
         return _TernLinear.apply(x, self.weight, self.bias, self.Wp, self.Wn, self, None)
 
 
@@ -235,6 +321,32 @@ class INQConv2d(nn.Module):
         return ops.conv_forward_codes(x.contiguous(), self.codes, self.codebook(), self.stride, self.padding)
 
 
+def quantize_all(ls):
+    """One quantiser call for all ternary layers of a model (five launches) instead of one per layer; with gradients on,
+    one autograd node per group of equal settings, whose backward applies the quantiser's gradient rule to all layers
+    in one call as well.  Each layer picks its result up in its next forward."""
+    if not ls:
+        return
+    for mode in ("twn", "ttq"):
+        grp = [l for l in ls if l.mode_q == mode]
+        for key in sorted({(l.factor, l.threshold_from_max) for l in grp}):
+            g = [l for l in grp if (l.factor, l.threshold_from_max) == key]
+            if torch.is_grad_enabled() and all(l.weight.requires_grad for l in g):
+                sink = []
+                ts = [l.weight for l in g] + ([l.Wp for l in g] + [l.Wn for l in g] if mode == "ttq" else [])
+                Wts = _QuantizeAll.apply(mode, key[0], key[1], len(g), sink, *ts)
+                for l, q, Wt in zip(g, sink, Wts):
+                    l._shared = (q, Wt)
+                continue
+            ws = [l.weight.detach() for l in g]
+            if mode == "ttq":
+                qs = ops.tern_forward(ws, "ttq", key[0], key[1], [l.Wp.detach() for l in g], [l.Wn.detach() for l in g])
+            else:
+                qs = ops.tern_forward(ws, "twn", key[0], key[1])
+            for l, q in zip(g, qs):
+                l._shared = q
+
+
 def make_conv(config, in_channel, out_channel, ksize=3, stride=1, padding=1):
     """Convolution of the flavour config.mode_q names ("twn" | "ttq" | "inq")."""
     mode_q = getattr(config, "mode_q", "twn")
@@ -294,21 +406,7 @@ class ResNet(nn.Module):
         return [m for m in self.modules() if isinstance(m, _TernBase)]
 
     def _quantize_all(self):
-        """One quantiser call for all ternary layers of the model (five launches) instead of one per layer."""
-        ls = self.quant_layers()
-        if not ls:
-            return
-        for mode in ("twn", "ttq"):
-            grp = [l for l in ls if l.mode_q == mode]
-            for key in {(l.factor, l.threshold_from_max) for l in grp}:
-                g = [l for l in grp if (l.factor, l.threshold_from_max) == key]
-                ws = [l.weight.detach() for l in g]
-                if mode == "ttq":
-                    qs = ops.tern_forward(ws, "ttq", key[0], key[1], [l.Wp.detach() for l in g], [l.Wn.detach() for l in g])
-                else:
-                    qs = ops.tern_forward(ws, "twn", key[0], key[1])
-                for l, q in zip(g, qs):
-                    l._shared = q
+        quantize_all(self.quant_layers())
 
     def forward(self, x):
         if not x.is_cuda:

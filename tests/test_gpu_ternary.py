@@ -207,3 +207,32 @@ def test_ternary_resnet20_trains_and_inq_stages():
     xin = torch.randn(2, m.weight.shape[1], 12, 12, device=DEV)
     with torch.no_grad():
         assert torch.equal(m.forward_codes(xin), m(xin)) or (m.forward_codes(xin) - m(xin)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("mode_q", ["twn", "ttq"])
+def test_model_wide_quantiser_node_equals_per_layer_path(mode_q, monkeypatch):
+    """ternary.ResNet quantises all layers in one call and applies the quantiser's gradient rule to all of them in one
+    call (one autograd node); every layer on its own (the path a single TernaryConv2d takes) must give the same
+    loss and the same gradients."""
+    torch.manual_seed(5)
+    c = argparse.Namespace(mode_q=mode_q)
+    model = T.ResNet(c, 1).to(DEV).train()
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    for m in model.modules():  # batch-norm running statistics would differ between the two passes otherwise
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    l1, g1 = grads()
+    monkeypatch.setattr(T, "quantize_all", lambda ls: None)
+    l2, g2 = grads()
+    assert l1 == l2
+    assert g1.keys() == g2.keys() and any(".Wp" in n for n in g1) == (mode_q == "ttq")
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]) or float((g1[n] - g2[n]).abs().max()) <= 1e-6 * float(g2[n].abs().max()), n
