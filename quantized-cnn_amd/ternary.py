@@ -192,6 +192,15 @@ class TernaryConv2d(_TernBase):
     def forward(self, x, res=None, bn=None, split=False):
         """Same call convention as layers.QConv2d.forward (res added to the output, bn applied to the input, split
         returns the raw input or its pooled shortcut next to the output)."""
+        if isinstance(self._shared, tuple) and torch.is_grad_enabled() and self.ksize == 3 and self.padding == 1:
+            # Training step of a model that quantised all its layers together (quantize_all): the decoded weights are an
+            # autograd tensor, so the layer runs on the same fused nodes as the adaptive layers (layers.QConv2d.forward):
+            # shortcut added in the convolution's epilogue, batch statistics out of the producing convolution,
+            # batch-norm backward coupled to the input-gradient kernel.
+            (q, Wt), self._shared = self._shared, None
+            if bn is not None:
+                return layers.bn_relu_conv(bn, x, Wt, self.stride, None, res, split, stats=self.training)
+            return layers.conv3x3(x, Wt, self.stride, None, res, stats=self.training, split=bool(split))
         xs = x
         if bn is not None:
             if split:
@@ -200,7 +209,7 @@ class TernaryConv2d(_TernBase):
                 z = layers.bn_relu(bn, x)
         else:
             z = x
-        if isinstance(self._shared, tuple) and torch.is_grad_enabled():  # quantised with the model's other layers (ResNet._quantize_all)
+        if isinstance(self._shared, tuple) and torch.is_grad_enabled():  # quantised with the model's other layers (quantize_all)
             (q, Wt), self._shared = self._shared, None
             y = _ConvFromQuantized.apply(z, Wt, self, q)
         else:

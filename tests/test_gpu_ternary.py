@@ -213,7 +213,7 @@ def test_ternary_resnet20_trains_and_inq_stages():
 def test_model_wide_quantiser_node_equals_per_layer_path(mode_q, monkeypatch):
     """ternary.ResNet quantises all layers in one call and applies the quantiser's gradient rule to all of them in one
     call (one autograd node); every layer on its own (the path a single TernaryConv2d takes) must give the same
-    loss and the same gradients."""
+    loss and the same gradients to rounding."""
     torch.manual_seed(5)
     c = argparse.Namespace(mode_q=mode_q)
     model = T.ResNet(c, 1).to(DEV).train()
@@ -232,7 +232,9 @@ def test_model_wide_quantiser_node_equals_per_layer_path(mode_q, monkeypatch):
     l1, g1 = grads()
     monkeypatch.setattr(T, "quantize_all", lambda ls: None)
     l2, g2 = grads()
-    assert l1 == l2
+    # (the model-wide path convolves with the decoded weights on the fused nodes of the adaptive layers, a single layer
+    # from its codes: other kernels, other summation order)
+    assert abs(l1 - l2) <= 2e-6 * abs(l2)
     assert g1.keys() == g2.keys() and any(".Wp" in n for n in g1) == (mode_q == "ttq")
     for n in g1:
-        assert torch.equal(g1[n], g2[n]) or float((g1[n] - g2[n]).abs().max()) <= 1e-6 * float(g2[n].abs().max()), n
+        assert float((g1[n] - g2[n]).abs().max()) <= 2e-4 * float(g2[n].abs().max()) + 1e-7, n
