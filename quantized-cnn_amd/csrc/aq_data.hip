@@ -47,18 +47,27 @@ struct AbsmaxTab {
     float *out;
 };
 
-// one workgroup per tensor: max |v| (exact, order-independent); NaN inputs are ignored like fmaxf does
+// max |v| per tensor (exact, order-independent); NaN inputs are ignored like fmaxf does.  Up to ABSMAX_SPLIT workgroups
+// share a tensor: each takes every gridDim.x-th run of 1024 elements and merges its maximum into out[i] with an
+// integer atomic max on the bit pattern (non-negative floats order like unsigned integers; out starts at +0), so the
+// result does not depend on arrival order.  (One workgroup per tensor took 2.1 ms on a 2.4 M-weight layer.)
+constexpr int ABSMAX_SPLIT = 128;
 __global__ __launch_bounds__(256) void absmax_kernel(const AbsmaxTab t)
 {
     __shared__ float sh[4];
-    const int i = blockIdx.x;
+    const int i = blockIdx.y;
+    const long long n = t.n[i];
+    const float *__restrict__ p = t.p[i];
     float m = 0.0f;
-    for (long long k = threadIdx.x; k < t.n[i]; k += 256) m = fmaxf(m, fabsf(t.p[i][k]));
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(p[k]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) t.out[i] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    if (threadIdx.x == 0) {
+        const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        if (r > 0.0f) atomicMax(reinterpret_cast<unsigned *>(t.out + i), __builtin_bit_cast(unsigned, r));
+    }
 }
 
 } // namespace aq
@@ -102,7 +111,12 @@ int aq_absmax(const float *const *tensors, const long long *sizes, int n, float 
             t.n[i] = sizes[base + i];
         }
         t.out = out + base;
-        hipLaunchKernelGGL(absmax_kernel, dim3(m), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+        long long most = 0;
+        for (int i = 0; i < m; ++i) most = most > t.n[i] ? most : t.n[i];
+        const int split = (int)(most / 4096 < 1 ? 1 : (most / 4096 > ABSMAX_SPLIT ? ABSMAX_SPLIT : most / 4096));
+        hipError_t e = hipMemsetAsync(out + base, 0, sizeof(float) * m, static_cast<hipStream_t>(stream));
+        AQ_REQUIRE(e == hipSuccess, -EIO, "aq_absmax: clearing the result failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(absmax_kernel, dim3(split, m), dim3(256), 0, static_cast<hipStream_t>(stream), t);
         if (int rc = check_launch("aq_absmax")) return rc;
     }
     return 0;

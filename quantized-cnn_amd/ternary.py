@@ -8,8 +8,10 @@ reference code: the arithmetic follows the papers (Li, Zhang, Liu 2016; Zhu, Han
     mode_q = "ttq" : w~ = +Wp / -Wn above / below +-delta with learned Wp, Wn; scaled straight-through gradients
     mode_q = "inq" : full-precision weights whose largest-magnitude share is frozen at powers of two, stage by stage
 
-Forward convolutions read the 1-byte codes and a three-entry codebook and decode them while the weight tile is
-staged into LDS (the scale rides in the codebook); the backward pass uses the decoded weights.
+A layer on its own, and every layer outside a training step, convolves from the 1-byte codes and a three-entry codebook,
+decoded while the weight tile is staged into LDS (the scale rides in the codebook); the backward pass uses the decoded
+weights.  In a training step of a model that quantises all its layers together (quantize_all) the decoded weights are
+an autograd tensor and the 3x3 layers run on the fused convolution nodes of the adaptive layers.
 """
 import math
 
