@@ -81,6 +81,7 @@ class ResNet18(nn.Module):
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._synthesize_all()
         ternary.quantize_all([m for m in self.modules() if isinstance(m, ternary._TernBase)])
+        ternary.inq_all([m for m in self.modules() if isinstance(m, ternary.INQConv2d)])
         c0 = self.conv0
         out = layers.conv3x3(x, c0.weight, 2, None, pad=3)
         out = self.pool0(layers.bn_relu(self.bn0, out))

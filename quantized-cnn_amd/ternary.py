@@ -246,15 +246,46 @@ class _InqMask(torch.autograd.Function):
     Adam's running averages)."""
 
     @staticmethod
-    def forward(ctx, w, mask, frozen):
+    def forward(ctx, w, mask, maskb, frozen):
         ctx.save_for_backward(w, mask)
-        return w.view_as(w) if frozen is None else torch.where(mask.bool(), w, frozen)
+        return w.view_as(w) if frozen is None else torch.where(maskb, w, frozen)
 
     @staticmethod
     def backward(ctx, g):
         w, mask = ctx.saved_tensors
         dW, _, _ = ops.tern_backward([w.detach()], [g.contiguous()], "inq", masks=[mask])
-        return dW[0], None, None
+        return dW[0], None, None, None
+
+
+class _InqAll(torch.autograd.Function):
+    """The effective weights of ALL INQ layers of a model as one autograd node, so that the masking of the gradients
+    (ops.tern_backward in its INQ mode) is one call for every layer instead of one per layer.
+    apply(layers, w_0, .., w_{n-1}) -> (W_0, .., W_{n-1})."""
+
+    @staticmethod
+    def forward(ctx, ls, *ws):
+        ctx.masks = [l.mask for l in ls]
+        ctx.save_for_backward(*ws)
+        outs = []
+        for l, w in zip(ls, ws):
+            maskb, frozen = l._frozen_values()
+            outs.append(w.view_as(w) if frozen is None else torch.where(maskb, w, frozen))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        ws = [w.detach() for w in ctx.saved_tensors]
+        dW, _, _ = ops.tern_backward(ws, [d.contiguous() for d in g], "inq", masks=ctx.masks)
+        return (None,) + tuple(dW)
+
+
+def inq_all(ls):
+    """Effective weights of all INQ layers of a model through one autograd node (training steps only); each layer picks
+    its weight up in its next forward."""
+    if not ls or not torch.is_grad_enabled() or not all(l.weight.requires_grad for l in ls):
+        return
+    for l, w in zip(ls, _InqAll.apply(ls, *[l.weight for l in ls])):
+        l._shared = w
 
 
 class INQConv2d(nn.Module):
@@ -271,6 +302,8 @@ class INQConv2d(nn.Module):
         self.register_buffer("codes", torch.full(self.weight.shape, 255, dtype=torch.uint8))
         self.register_buffer("exponents", torch.zeros(2, dtype=torch.int32))  # (n1, n2), fixed at the first stage
         self._have_exp = False
+        self._shared = None  # effective weight handed down by the owning model for the current step (inq_all)
+        self._cache = None
 
     def quantize_portion(self, fraction):
         """Freeze the largest-magnitude weights until `fraction` of all weights are frozen."""
@@ -291,17 +324,27 @@ class INQConv2d(nn.Module):
         tau = float(torch.topk(free, min(k, free.numel()), largest=True, sorted=True).values[-1])
         n1, n2 = (int(v) for v in self.exponents.tolist())
         ops.inq_partition(w, self.mask, tau, n1, n2, self.codes)
-        self._q = None
+        self._cache = None  # (the kernel wrote mask and codes behind torch's version counters)
         return k
+
+    def _frozen_values(self):
+        """-> (boolean mask, fp32 values of the frozen weights decoded from the codes), or (None, None) before the first
+        stage.  Cached: recomputed after quantize_portion and whenever the buffers were written (state_dict loads)."""
+        if not self._have_exp:
+            return None, None
+        key = (self.codes._version, self.mask._version, self.exponents._version, self.weight.device)
+        if getattr(self, "_cache", None) is None or self._cache[0] != key:
+            q = self.codebook()
+            self._cache = (key, self.mask.bool(), q[self.codes.clamp(max=q.numel() - 1).long()])
+        return self._cache[1], self._cache[2]
 
     def effective_weight(self):
         """The weights the layer computes with: trainable entries from the parameter, frozen ones from their codes."""
-        if not self._have_exp:
-            return _InqMask.apply(self.weight, self.mask, None)
-        if getattr(self, "_q", None) is None or self._q.device != self.weight.device:
-            self._q = self.codebook()
-        frozen = self._q[self.codes.clamp(max=self._q.numel() - 1).long()]
-        return _InqMask.apply(self.weight, self.mask, frozen)
+        if self._shared is not None and torch.is_grad_enabled():  # computed with the model's other layers (inq_all)
+            w, self._shared = self._shared, None
+            return w
+        maskb, frozen = self._frozen_values()
+        return _InqMask.apply(self.weight, self.mask, maskb, frozen)
 
     def codebook(self):
         """Level table of `codes`: index 0 = 0, 1 + 2 * (k - n2) + s = (-1)^s * 2^k."""
@@ -312,6 +355,9 @@ class INQConv2d(nn.Module):
         return torch.tensor(q, dtype=torch.float32, device=self.weight.device)
 
     def forward(self, x, res=None, bn=None, split=False):
+        if bn is not None and self.ksize == 3 and self.padding == 1 and torch.is_grad_enabled():
+            # the fused nodes of the adaptive layers (layers.QConv2d.forward)
+            return layers.bn_relu_conv(bn, x, self.effective_weight(), self.stride, None, res, split, stats=self.training)
         xs = x
         if bn is not None:
             if split:
@@ -423,6 +469,7 @@ class ResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._quantize_all()
+        inq_all([m for m in self.modules() if isinstance(m, INQConv2d)])
         c0 = self.conv0
         out = layers.conv3x3(x, c0.weight, 1, None)
         out = layers.bn_relu(self.bn0, out)

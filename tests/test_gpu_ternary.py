@@ -238,3 +238,33 @@ def test_model_wide_quantiser_node_equals_per_layer_path(mode_q, monkeypatch):
     assert g1.keys() == g2.keys() and any(".Wp" in n for n in g1) == (mode_q == "ttq")
     for n in g1:
         assert float((g1[n] - g2[n]).abs().max()) <= 2e-4 * float(g2[n].abs().max()) + 1e-7, n
+
+
+def test_model_wide_inq_node_equals_per_layer_path(monkeypatch):
+    """ternary.ResNet hands every INQ layer its effective weight from one autograd node (gradients masked for all layers in
+    one call); each layer computing its own must give the same loss and gradients bit for bit (same kernels, same order)."""
+    torch.manual_seed(9)
+    c = argparse.Namespace(mode_q="inq")
+    model = T.ResNet(c, 1).to(DEV).train()
+    for m in model.modules():
+        if isinstance(m, T.INQConv2d):
+            m.quantize_portion(0.5)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l1, g1 = grads()
+    monkeypatch.setattr(T, "inq_all", lambda ls: None)
+    l2, g2 = grads()
+    assert l1 == l2 and g1.keys() == g2.keys()
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    frozen = [m for m in model.modules() if isinstance(m, T.INQConv2d)][0]
+    assert float(frozen.weight.grad[frozen.mask == 0].abs().max()) == 0.0
