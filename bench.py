@@ -250,6 +250,42 @@ def ternary_step(steps=100, warmup=20):
     return out
 
 
+def inq_resnet18(steps=20, warmup=5, batch=32):
+    """BASELINE configs[2] read literally: ResNet-18 at 224 x 224 with INQ convolutions (5-bit powers of two, half of the
+    weights frozen), synthetic data, batch 32 per GPU: forward, cross entropy, backward, SGD with momentum as one HIP graph
+    (train.CapturedStep).  No reference model or INQ implementation exists: parity unpinned."""
+    from quantized_cnn_amd.resnet18 import ResNet18
+    from quantized_cnn_amd.train import CapturedStep
+    import quantized_cnn_amd.adp_qtz_fan as fan
+    c = cfg()
+    c.mode_q = "inq"
+    torch.manual_seed(0)
+    model = ResNet18(c, fan).cuda().train()
+    for m in model.modules():
+        if hasattr(m, "quantize_portion"):
+            m.quantize_portion(0.5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    step = CapturedStep(model, opt, torch.nn.functional.cross_entropy)
+    g = torch.Generator(device="cuda").manual_seed(1000)
+    x = torch.randn(batch, 3, 224, 224, device="cuda", generator=g)
+    y = torch.randint(0, 1000, (batch,), device="cuda", generator=g)
+    for _ in range(warmup):
+        step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del model, opt, step
+    torch.cuda.empty_cache()
+    return {"value": round(batch / dt, 1), "unit": "img/s", "ms_per_step": round(dt * 1e3, 3), "final_loss": round(float(loss), 5),
+            "conv_tflops": round(3 * 1.8e9 * batch / dt / 1e12, 1),
+            "workload": "ResNet-18 @224 with INQ convolutions (5 bits, 50 %% frozen), batch %d, synthetic ImageNet-shaped data, "
+                        "train.CapturedStep: fwd + CE + bwd + SGD(momentum) in one HIP graph" % batch,
+            "parity": "unpinned (no reference implementation)"}
+
+
 def cpu_baseline(quick):
     """CPU port of the same step (oracle/torch_port.py, pinned to the reference by tests) on the host."""
     from oracle import torch_port as TP
@@ -397,6 +433,7 @@ def main():
             out["roofline"] = roof
             out["roofline_more"] = more
             out["ternary_resnet20"] = ternary_step(20 if args.quick else 100, 5 if args.quick else 20)
+            out["inq_resnet18"] = inq_resnet18(5 if args.quick else 20, 2 if args.quick else 5)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.quick)
         print(json.dumps(out), flush=True)

@@ -177,6 +177,61 @@ class TrainStep:
         self._graph = g
 
 
+class CapturedStep:
+    """A training step of any model on torch autograd with torch optimizers - forward, loss_fn(model(x), y), backward,
+    optimizer.step() - captured once and replayed as ONE HIP graph (the library's kernels are launched on torch's current
+    stream, so they are captured like stock operators).  For the models outside the reference's three-optimizer loop
+    (ternary.ResNet, resnet18.ResNet18, single layers); the reference's own step order is TrainStep / FusedTrainStep.
+    `warmup` (>= 1) eager steps on the first batch run first (they are real steps: optimizer state is created there), then
+    the capture; every call
+    copies (x, y) into the graph's input buffers and replays.  Shapes must stay fixed; SyncBatchNorm is refused."""
+
+    def __init__(self, model, optimizers, loss_fn, warmup=2):
+        if warmup < 1:  # optimizers create their state (momentum, Adam's averages) in their first step: a capture of THAT
+            # step would replay the state's creation, not its update
+            raise ValueError("CapturedStep: at least one eager warm-up step is needed before the capture")
+        self.model, self.loss_fn, self.warmup = model, loss_fn, warmup
+        self.opts = list(optimizers) if isinstance(optimizers, (list, tuple)) else [optimizers]
+        self._graph = None
+
+    def _body(self):
+        out = self.model(self._sx)
+        loss = self.loss_fn(out, self._sy)
+        loss.backward()
+        for o in self.opts:
+            o.step()
+        self.loss, self.output = loss.detach(), out.detach()
+
+    def _capture(self, x, y):
+        if any(isinstance(m, nn.SyncBatchNorm) for m in self.model.modules()):
+            raise RuntimeError("CapturedStep: the model holds SyncBatchNorm modules; their collectives cannot be captured in a HIP graph")
+        self._sx, self._sy = x.clone(), y.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                for o in self.opts:
+                    o.zero_grad(set_to_none=True)
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        for o in self.opts:
+            o.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self._graph = g
+
+    def __call__(self, x, y):
+        if self._graph is None:
+            self._capture(x, y)  # (the capture itself does not execute: the replay below is this call's step)
+        elif tuple(x.shape) != tuple(self._sx.shape) or tuple(y.shape) != tuple(self._sy.shape):
+            raise ValueError("CapturedStep: batch shape changed (%s -> %s); build a new step" % (tuple(self._sx.shape), tuple(x.shape)))
+        self._sx.copy_(x)
+        self._sy.copy_(y)
+        self._graph.replay()
+        return self.loss
+
+
 def _refuse_sync_bn_under_capture(model, dp):
     """SyncBatchNorm runs torch.distributed collectives inside its forward and backward; captured into a HIP
     graph they would be replayed outside the process group's ordering.  Such a model runs eagerly."""

@@ -76,26 +76,10 @@ def main():
         print("ResNet-18 %s batch %d: %.1f ms/step, %.0f img/s, loss %.4f -> %.4f; conv flops %.1f GFLOP/step = %.1f TF/s" % (
             mode, B, t * 1e3, B / t, l0, float(step()), 3 * 1.8 * B, 3 * 1.8e9 * B / t / 1e12), flush=True)
         if a.graph:  # the same step captured once and replayed as one HIP graph
-            box = [None]
-
-            def body():
-                loss = torch.nn.functional.cross_entropy(model(x), y)
-                loss.backward()
-                opt.step()
-                box[0] = loss.detach()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    opt.zero_grad(set_to_none=True)
-                    body()
-            torch.cuda.current_stream().wait_stream(s)
-            gr = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(gr):
-                body()
-            tg = ev(gr.replay, 10, 2)
-            print("ResNet-18 %s batch %d as one HIP graph: %.2f ms/step, %.0f img/s, loss %.4f" % (mode, B, tg * 1e3, B / tg, float(box[0])), flush=True)
+            from quantized_cnn_amd.train import CapturedStep
+            cs = CapturedStep(model, opt, torch.nn.functional.cross_entropy)
+            tg = ev(lambda: cs(x, y), 10, 2)
+            print("ResNet-18 %s batch %d as one HIP graph: %.2f ms/step, %.0f img/s, loss %.4f" % (mode, B, tg * 1e3, B / tg, float(cs.loss)), flush=True)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantized_cnn_amd import ternary  # noqa: E402
+from quantized_cnn_amd.train import CapturedStep  # noqa: E402
 
 
 def timed(fn, iters, warm):
@@ -40,30 +41,6 @@ def build(mode, batch):
     return model, opt, x, y
 
 
-def graph_step(model, opt, x, y):
-    """-> (replay function, loss tensor): the whole step captured once, after three eager steps on a side stream."""
-    loss_box = [None]
-
-    def step():
-        loss = torch.nn.functional.cross_entropy(model(x), y)
-        loss.backward()
-        opt.step()
-        loss_box[0] = loss.detach()
-
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            opt.zero_grad(set_to_none=True)
-            step()
-    torch.cuda.current_stream().wait_stream(s)
-    gr = torch.cuda.CUDAGraph()
-    opt.zero_grad(set_to_none=True)
-    with torch.cuda.graph(gr):
-        step()
-    return gr.replay, loss_box
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--modes", default="ttq,twn,inq")
@@ -81,10 +58,10 @@ def main():
         l0 = float(eager())
         te = timed(eager, 20, 5)
         model, opt, x, y = build(mode, a.batch)
-        replay, box = graph_step(model, opt, x, y)
-        tg = timed(replay, 100, 20)
+        step = CapturedStep(model, opt, torch.nn.functional.cross_entropy, warmup=3)
+        tg = timed(lambda: step(x, y), 100, 20)
         print("ResNet-20 %s batch %d: eager %.3f ms/step %.0f img/s | one HIP graph %.3f ms/step %.0f img/s | loss %.4f -> %.4f" % (
-            mode, a.batch, te * 1e3, a.batch / te, tg * 1e3, a.batch / tg, l0, float(box[0])), flush=True)
+            mode, a.batch, te * 1e3, a.batch / te, tg * 1e3, a.batch / tg, l0, float(step.loss)), flush=True)
 
 
 if __name__ == "__main__":

@@ -268,3 +268,36 @@ def test_model_wide_inq_node_equals_per_layer_path(monkeypatch):
         assert torch.equal(g1[n], g2[n]), n
     frozen = [m for m in model.modules() if isinstance(m, T.INQConv2d)][0]
     assert float(frozen.weight.grad[frozen.mask == 0].abs().max()) == 0.0
+
+
+def test_captured_step_replays_the_eager_steps():
+    """train.CapturedStep (the whole step as one HIP graph) against the same steps run eagerly from the same start:
+    same kernels in the same order, so parameters, momentum buffers and batch-norm statistics agree bit for bit."""
+    from quantized_cnn_amd.train import CapturedStep
+    c = argparse.Namespace(mode_q="ttq")
+    xs = [torch.randn(8, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(20 + i)) for i in range(5)]
+    ys = [torch.randint(0, 10, (8,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(40 + i)) for i in range(5)]
+
+    def fresh():
+        torch.manual_seed(1)
+        model = T.ResNet(c, 1).to(DEV).train()
+        return model, torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+
+    m1, o1 = fresh()
+    eager_losses = []
+    for x, y in zip(xs[:1] + xs, ys[:1] + ys):  # (the captured step's one warm-up step is a real step on the first batch)
+        o1.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m1(x), y)
+        loss.backward()
+        o1.step()
+        eager_losses.append(float(loss.detach()))
+    m2, o2 = fresh()
+    with pytest.raises(ValueError):
+        CapturedStep(m2, o2, torch.nn.functional.cross_entropy, warmup=0)
+    step = CapturedStep(m2, o2, torch.nn.functional.cross_entropy, warmup=1)
+    graph_losses = [float(step(x, y)) for x, y in zip(xs, ys)]
+    assert graph_losses == eager_losses[1:]
+    for (n, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), n
+    with pytest.raises(ValueError):
+        step(xs[0][:4], ys[0][:4])
