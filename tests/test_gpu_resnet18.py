@@ -1,0 +1,109 @@
+"""resnet18.ResNet18 (the torchvision ResNet-18 layout over the general convolution kernels; the reference holds no such
+model and no ternary / INQ quantiser: parity unpinned).  With INQ layers before their first stage the network is a
+plain fp32 ResNet-18, so loss and every gradient can be checked against the same network written with stock torch
+operators; the quantised modes are checked for what the papers prescribe (ternary codes, frozen powers of two) and for
+a training step that learns.  Inputs are 64 x 64 so that the file runs in seconds; the layer shapes at 224 x 224 are
+covered kernel by kernel in test_gpu_conv_general.py."""
+import argparse
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from quantized_cnn_amd import ternary as T
+    from quantized_cnn_amd.resnet18 import ResNet18
+    from quantized_cnn_amd.train import CapturedStep
+DEV = "cuda"
+
+
+def config(mode_q):
+    return argparse.Namespace(mode="train", mode_q=mode_q, prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=1e-4)
+
+
+def stock_forward(model, x):
+    """The same network through torch's own operators (batch statistics, no running-average update)."""
+    def bn(m, t):
+        return F.batch_norm(t, None, None, m.weight, m.bias, True, 0.0, m.eps)
+    out = F.max_pool2d(F.relu(bn(model.bn0, F.conv2d(x, model.conv0.weight, stride=2, padding=3))), 3, 2, 1)
+    for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in layer:
+            o = F.relu(bn(blk.bn1, F.conv2d(out, blk.conv1.weight, stride=blk.conv1.stride, padding=1)))
+            o = bn(blk.bn2, F.conv2d(o, blk.conv2.weight, stride=1, padding=1))
+            sc = out if blk.down is None else bn(blk.bn_down, F.conv2d(out, blk.down.weight, stride=blk.down.stride))
+            out = F.relu(o + sc)
+    return model.fc(torch.flatten(F.adaptive_avg_pool2d(out, 1), 1))
+
+
+def test_unfrozen_inq_resnet18_equals_the_stock_network():
+    torch.manual_seed(0)
+    model = ResNet18(config("inq"), num_classes=10).to(DEV).train()
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    loss = F.cross_entropy(model(x), y)
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    ref = F.cross_entropy(stock_forward(model, x), y)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    for n, p in model.named_parameters():
+        assert p.grad is not None and got[n] is not None, n
+        err = float((got[n] - p.grad).abs().max())
+        assert err <= 2e-3 * float(p.grad.abs().max()) + 1e-7, (n, err, float(p.grad.abs().max()))  # (17 layers of fp32 in another summation order)
+
+
+@pytest.mark.parametrize("mode_q", ["adaptive", "twn", "ttq", "inq"])
+def test_resnet18_training_step_learns_in_every_quantiser_mode(mode_q):
+    torch.manual_seed(1)
+    model = ResNet18(config(mode_q), num_classes=10).to(DEV).train()
+    if mode_q == "inq":
+        for m in model.modules():
+            if isinstance(m, T.INQConv2d):
+                m.quantize_portion(0.5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+    x = torch.randn(8, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters()), mode_q
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], (mode_q, losses)
+    if mode_q in ("twn", "ttq"):  # every layer computes with three values
+        for m in model.modules():
+            if isinstance(m, T.TernaryConv2d):
+                assert m.quantize()["Wt"].unique().numel() <= 3
+    if mode_q == "inq":  # frozen weights are powers of two (or zero) and receive no gradient
+        for m in model.modules():
+            if isinstance(m, T.INQConv2d):
+                fz = m.effective_weight().detach()[m.mask == 0].abs()
+                nz = fz[fz > 0]
+                assert torch.equal(torch.log2(nz), torch.log2(nz).round())
+                assert float(m.weight.grad[m.mask == 0].abs().max()) == 0.0
+
+
+def test_resnet18_step_as_one_graph_equals_eager_steps():
+    def fresh():
+        torch.manual_seed(2)
+        model = ResNet18(config("ttq"), num_classes=10).to(DEV).train()
+        return model, torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    m1, o1 = fresh()
+    eager = []
+    for _ in range(4):
+        o1.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(m1(x), y)
+        loss.backward()
+        o1.step()
+        eager.append(float(loss.detach()))
+    m2, o2 = fresh()
+    step = CapturedStep(m2, o2, F.cross_entropy, warmup=1)
+    graph = [float(step(x, y)) for _ in range(3)]
+    assert graph == eager[1:]
