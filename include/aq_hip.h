@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 10
+#define AQ_ABI_VERSION 11
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -283,6 +283,12 @@ int aq_shortcut_fwd(const float *x, float *y, int N, int C, int H, int Wd, int p
                     void *stream);
 int aq_shortcut_bwd(const float *dy, float *dx, int N, int C, int H, int Wd, int pad_front, int pad_back,
                     void *stream);
+
+/* nn.MaxPool2d(3, 2, 1) and its gradient for the stem of resnet18.py (the reference's models pool with AvgPool2d
+ * only, adp_qtz_fan.py:669-671, 716: no counterpart there).  y[N, C, OH, OW], OH = (H - 1) / 2 + 1; idx[N, C, OH, OW]
+ * = position ky * 3 + kx of the window's first maximum (NaN wins, as in torch); dx[N, C, H, W] gathers dy through idx. */
+int aq_maxpool3s2_fwd(const float *x, float *y, uint8_t *idx, int N, int C, int H, int Wd, void *stream);
+int aq_maxpool3s2_bwd(const float *dy, const uint8_t *idx, float *dx, int N, int C, int H, int Wd, void *stream);
 
 /* Packed storage of hard-mode weights: the codes idx = argmax s_c (adp_qtz_fan_test.py:304; values < L)
  * as a little-endian bit stream, `bits` (1..8; 5 for L = 31 / 32) bits per code, code i in stream bits

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -28,7 +28,7 @@ EXPORTS = (
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
     "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
     "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition",
-    "aq_pkt_workspace_bytes", "aq_pkt_loss", "aq_pkt_kernel_matrix",
+    "aq_pkt_workspace_bytes", "aq_pkt_loss", "aq_pkt_kernel_matrix", "aq_maxpool3s2_fwd", "aq_maxpool3s2_bwd",
 )
 TERN_TWN, TERN_TTQ, TERN_INQ = 0, 1, 2
 
@@ -121,6 +121,8 @@ def lib():
         L.aq_bn_relu_fwd_shortcut.restype = i
         L.aq_shortcut_fwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.aq_shortcut_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+        L.aq_maxpool3s2_fwd.argtypes = [vp, vp, vp, i, i, i, i, vp]
+        L.aq_maxpool3s2_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp]
         L.aq_packed_bytes.argtypes = [C.c_longlong, i]
         L.aq_packed_bytes.restype = sz
         L.aq_pack_codes.argtypes = [vp, C.c_longlong, i, vp, vp]

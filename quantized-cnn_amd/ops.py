@@ -461,6 +461,29 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
     return dx, dg, db
 
 
+# -------------------------------------------------------------------------------------- max pool
+
+def maxpool3s2_forward(x):
+    """nn.MaxPool2d(3, 2, 1) -> (y, idx): idx uint8 = position ky * 3 + kx of each window's first maximum."""
+    N, Cn, H, Wd = x.shape
+    OH, OW = (H - 1) // 2 + 1, (Wd - 1) // 2 + 1
+    y = torch.empty((N, Cn, OH, OW), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, Cn, OH, OW), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_maxpool3s2_fwd(_lib.ptr(x, name="x"), _lib.ptr(y), _lib.ptr(idx, torch.uint8, "idx"), int(N), int(Cn), int(H), int(Wd),
+                                            _lib.stream()))
+    return y, idx
+
+
+def maxpool3s2_backward(dy, idx, x_shape):
+    N, Cn, H, Wd = x_shape
+    if tuple(dy.shape) != (N, Cn, (H - 1) // 2 + 1, (Wd - 1) // 2 + 1) or tuple(idx.shape) != tuple(dy.shape):
+        raise ValueError("maxpool3s2_backward: dy %s / idx %s do not match x %s" % (tuple(dy.shape), tuple(idx.shape), tuple(x_shape)))
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().aq_maxpool3s2_bwd(_lib.ptr(dy, name="dy"), _lib.ptr(idx, torch.uint8, "idx"), _lib.ptr(dx), int(N), int(Cn), int(H), int(Wd),
+                                            _lib.stream()))
+    return dx
+
+
 # -------------------------------------------------------------------------------------- shortcut
 
 def shortcut_forward(x, pad_front, pad_back):

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import layers, ternary
+from . import layers, ops, ternary
 
 
 def _conv(config, module, cin, cout, ks, stride, pad):
@@ -23,6 +23,33 @@ def _conv(config, module, cin, cout, ks, stride, pad):
     if mode_q == "adaptive":
         return module.MyConv2d(config, cin, cout, ks, stride, pad)
     return ternary.make_conv(config, cin, cout, ks, stride, pad)
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on the library's kernels: a one-byte window position per output instead of torch's 8-byte
+    index, and a gather in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y, idx = ops.maxpool3s2_forward(x)
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3s2_backward(dy.contiguous(), idx, ctx.shape)
+
+
+def max_pool_3s2(pool, x):
+    """pool(x) for the stem's nn.MaxPool2d; the library's kernels when it is the usual (3, 2, 1) pool on a HIP fp32 tensor."""
+    usual = (pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2)) and pool.padding in (1, (1, 1)) and pool.dilation in (1, (1, 1))
+             and not pool.ceil_mode and not pool.return_indices)
+    if usual and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        return _MaxPool3s2.apply(x)
+    return pool(x)
 
 
 class BasicBlock(nn.Module):
@@ -84,7 +111,7 @@ class ResNet18(nn.Module):
         ternary.inq_all([m for m in self.modules() if isinstance(m, ternary.INQConv2d)])
         c0 = self.conv0
         out = layers.conv3x3(x, c0.weight, 2, None, pad=3)
-        out = self.pool0(layers.bn_relu(self.bn0, out))
+        out = max_pool_3s2(self.pool0, layers.bn_relu(self.bn0, out))
         out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
         out = torch.flatten(F.adaptive_avg_pool2d(out, 1), 1)
         return self.fc(out)

@@ -107,3 +107,33 @@ def test_resnet18_step_as_one_graph_equals_eager_steps():
     step = CapturedStep(m2, o2, F.cross_entropy, warmup=1)
     graph = [float(step(x, y)) for _ in range(3)]
     assert graph == eager[1:]
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (3, 5, 7, 9), (1, 2, 1, 1), (2, 4, 2, 3), (4, 64, 56, 56), (1, 1, 113, 31)])
+def test_max_pool_kernels_equal_torch(shape):
+    """aq_maxpool3s2_fwd / _bwd against nn.MaxPool2d(3, 2, 1): values bit-equal; gradients equal (an input pixel sums at most
+    four window gradients); ties (quantised inputs) route the gradient to the first maximum in scan order as torch does."""
+    import quantized_cnn_amd.ops as ops
+    from quantized_cnn_amd.resnet18 import max_pool_3s2
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    for ties in (False, True):
+        x = torch.randn(shape, device=DEV, generator=g)
+        if ties:
+            x = (x * 2).round() / 2
+        pool = torch.nn.MaxPool2d(3, 2, 1)
+        xr = x.clone().requires_grad_(True)
+        yr = pool(xr)
+        dy = torch.randn(yr.shape, device=DEV, generator=g)
+        yr.backward(dy)
+        xg = x.clone().requires_grad_(True)
+        y = max_pool_3s2(pool, xg)
+        assert torch.equal(y, yr)
+        y.backward(dy)
+        assert float((xg.grad - xr.grad).abs().max()) <= 1e-6 * max(float(xr.grad.abs().max()), 1e-6)
+        y2, idx = ops.maxpool3s2_forward(x)
+        assert int(idx.max()) <= 8 and torch.equal(y2, yr.detach())
+    xn = torch.randn(1, 1, 6, 6, device=DEV)
+    xn[0, 0, 2, 2] = float("nan")
+    yn, yt = ops.maxpool3s2_forward(xn)[0], torch.nn.functional.max_pool2d(xn, 3, 2, 1)
+    assert torch.equal(torch.isnan(yn), torch.isnan(yt)) and torch.equal(yn[~torch.isnan(yn)], yt[~torch.isnan(yt)])
+    assert max_pool_3s2(torch.nn.MaxPool2d(2, 2), xn[:, :, :4, :4].nan_to_num()).shape == (1, 1, 2, 2)  # other pools: stock operator
