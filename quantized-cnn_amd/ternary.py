@@ -305,6 +305,13 @@ class INQConv2d(nn.Module):
         self._shared = None  # effective weight handed down by the owning model for the current step (inq_all)
         self._cache = None
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """mask / codes / exponents travel with the state_dict; whether a first stage has fixed the exponents is derived
+        from them, so that a reloaded layer computes with its frozen levels and continues its stages."""
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._have_exp = bool((self.mask == 0).any()) or bool(self.exponents.any())
+        self._cache = None
+
     def quantize_portion(self, fraction):
         """Freeze the largest-magnitude weights until `fraction` of all weights are frozen."""
         w = self.weight.data

@@ -301,3 +301,24 @@ def test_captured_step_replays_the_eager_steps():
         assert torch.equal(a, b), n
     with pytest.raises(ValueError):
         step(xs[0][:4], ys[0][:4])
+
+
+def test_inq_layer_survives_a_state_dict_round_trip():
+    """mask, codes and exponents are buffers: a layer rebuilt from a state_dict computes with the same frozen levels,
+    keeps them out of the gradient, and continues with the next stage on the same exponents."""
+    torch.manual_seed(4)
+    a = T.INQConv2d(16, 32, 3, 1, 1).to(DEV)
+    a.quantize_portion(0.5)
+    b = T.INQConv2d(16, 32, 3, 1, 1).to(DEV)
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a.effective_weight().detach(), b.effective_weight().detach())
+    assert torch.equal(a.exponents, b.exponents)
+    with torch.no_grad():
+        b.weight.add_(0.123)  # whatever an optimizer does to the frozen coordinates must not show
+    eff = b.effective_weight().detach()
+    assert torch.equal(eff[b.mask == 0], a.effective_weight().detach()[a.mask == 0])
+    x = torch.randn(2, 16, 8, 8, device=DEV)
+    b(x).sum().backward()
+    assert float(b.weight.grad[b.mask == 0].abs().max()) == 0.0
+    b.quantize_portion(0.75)
+    assert abs(1.0 - float(b.mask.float().mean()) - 0.75) <= 1e-3 and torch.equal(a.exponents, b.exponents)
