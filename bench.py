@@ -175,7 +175,7 @@ def kernel_rooflines(quick):
                 cin, cout, s, H, H, BATCH, nl), "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
             del xs, dys, outs
-    # ---- kernels of the quantiser modes and shapes that have no reference code (parity unpinned; see DESIGN.md) ----
+    # ---- kernels of the quantiser modes and shapes that have no reference code (parity unpinned) ----
     torch.cuda.empty_cache()
     n = 250_000_000 if not quick else 25_000_000
     w = torch.randn(n, device=dev) * 0.05
