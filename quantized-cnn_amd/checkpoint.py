@@ -80,23 +80,42 @@ def _load_optimizer(opt, state):
                     st[k] = prev
 
 
+_ROLE_KEYS = (("prim", "optimizer_prim"), ("q", "optimizer_q"), ("rest", "optimizer"))
+
+
+def _by_role(opts):
+    """{role: optimizer} for train.OptimizerSet (models without p_c / q_level hold fewer than three optimizers), or
+    for a plain sequence of exactly three in the reference's order (optimizer_prim, optimizer_q, optimizer)."""
+    roles = getattr(opts, "roles", None)
+    if roles is None:
+        if len(opts) != 3:
+            raise ValueError("checkpoint: %d optimizers without roles; pass train.make_optimizers' result or the reference's "
+                             "three (optimizer_prim, optimizer_q, optimizer)" % len(opts))
+        roles = ("prim", "q", "rest")
+    return dict(zip(roles, opts))
+
+
 def save_checkpoint(path, model, opts, beta, epoch, iter_idx, best_val_acc):
-    """adp_qtz_fan.py:331-340.  opts = (optimizer_prim, optimizer_q, optimizer)."""
-    torch.save({
+    """adp_qtz_fan.py:331-340.  opts = (optimizer_prim, optimizer_q, optimizer) or a train.OptimizerSet; a group the
+    model does not have (ternary / INQ models: no p_c, no q_level) is written as an empty Adam state_dict, so the file
+    keeps the reference's eight keys."""
+    by = _by_role(opts)
+    empty = {"state": {}, "param_groups": []}
+    res = {
         "beta": _plain(beta),
         "epoch": int(epoch),
         "iter_idx": int(iter_idx),
         "best_val_acc": float(_plain(best_val_acc)),
         "model": model.state_dict(),
-        "optimizer_prim": opts[0].state_dict(),
-        "optimizer_q": opts[1].state_dict(),
-        "optimizer": opts[2].state_dict(),
-    }, path)
+    }
+    for role, key in _ROLE_KEYS:
+        res[key] = by[role].state_dict() if role in by else dict(empty)
+    torch.save(res, path)
 
 
 def load_checkpoint(path, model, opts=None):
-    """adp_qtz_fan.py:249-263: restores the model and (when given) the three optimizers; returns
-    (beta, start_epoch, iter_idx, best_val_acc).  The caller assigns beta to the variant module's global
+    """adp_qtz_fan.py:249-263: restores the model and (when given) the optimizers, each from the entry of its role;
+    returns (beta, start_epoch, iter_idx, best_val_acc).  The caller assigns beta to the variant module's global
     (`adp_qtz_fan.beta = beta`)."""
     res = _safe_load(path)
     missing = [k for k in CHECKPOINT_KEYS if k not in res]
@@ -104,8 +123,14 @@ def load_checkpoint(path, model, opts=None):
         raise KeyError("%s is not a training checkpoint: missing %s" % (path, missing))
     model.load_state_dict(res["model"])
     if opts is not None:
-        for o, k in zip(opts, ("optimizer_prim", "optimizer_q", "optimizer")):
-            _load_optimizer(o, res[k])
+        by = _by_role(opts)
+        for role, key in _ROLE_KEYS:
+            if role in by:
+                if not res[key].get("param_groups"):
+                    raise KeyError("%s holds no state for the %r optimizer of this model" % (path, key))
+                _load_optimizer(by[role], res[key])
+            elif res[key].get("param_groups"):
+                raise KeyError("%s holds %r state, but the model has no such parameter group" % (path, key))
     return _plain(res["beta"]), int(res["epoch"]), int(res["iter_idx"]), float(_plain(res["best_val_acc"]))
 
 

@@ -248,7 +248,7 @@ class _InqMask(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, mask, maskb, frozen):
         ctx.save_for_backward(w, mask)
-        return w.view_as(w) if frozen is None else torch.where(maskb, w, frozen)
+        return torch.where(maskb, w, frozen)
 
     @staticmethod
     def backward(ctx, g):
@@ -269,7 +269,7 @@ class _InqAll(torch.autograd.Function):
         outs = []
         for l, w in zip(ls, ws):
             maskb, frozen = l._frozen_values()
-            outs.append(w.view_as(w) if frozen is None else torch.where(maskb, w, frozen))
+            outs.append(torch.where(maskb, w, frozen))
         return tuple(outs)
 
     @staticmethod
@@ -310,7 +310,7 @@ class INQConv2d(nn.Module):
         from them, so that a reloaded layer computes with its frozen levels and continues its stages."""
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
         self._have_exp = bool((self.mask == 0).any()) or bool(self.exponents.any())
-        self._cache = None
+        self._refresh_frozen()
 
     def quantize_portion(self, fraction):
         """Freeze the largest-magnitude weights until `fraction` of all weights are frozen."""
@@ -331,18 +331,36 @@ class INQConv2d(nn.Module):
         tau = float(torch.topk(free, min(k, free.numel()), largest=True, sorted=True).values[-1])
         n1, n2 = (int(v) for v in self.exponents.tolist())
         ops.inq_partition(w, self.mask, tau, n1, n2, self.codes)
-        self._cache = None  # (the kernel wrote mask and codes behind torch's version counters)
+        self._refresh_frozen()  # (the kernel wrote mask and codes behind torch's version counters)
         return k
 
+    def _refresh_frozen(self):
+        """Bring the boolean mask and the decoded frozen values up to date with the buffers.  The two tensors are
+        allocated once per device and from then on written IN PLACE: a training step captured as a HIP graph
+        (train.CapturedStep, TrainStep(use_graph=True)) holds their addresses, so a new INQ stage or a state_dict load
+        must change their contents, not replace them - replaced tensors would leave the replayed graph reading freed
+        memory and the previous partition."""
+        dev = self.weight.device
+        q = self.codebook()
+        maskb = self.mask.bool()
+        frozen = q[self.codes.clamp(max=q.numel() - 1).long()]
+        c = self._cache
+        if c is None or c[1].device != dev or c[1].shape != maskb.shape:
+            self._cache = c = [None, maskb, frozen]
+        else:
+            c[1].copy_(maskb)
+            c[2].copy_(frozen)
+        c[0] = (self.codes._version, self.mask._version, self.exponents._version, dev)
+
     def _frozen_values(self):
-        """-> (boolean mask, fp32 values of the frozen weights decoded from the codes), or (None, None) before the first
-        stage.  Cached: recomputed after quantize_portion and whenever the buffers were written (state_dict loads)."""
-        if not self._have_exp:
-            return None, None
+        """-> (boolean mask of the trainable weights, fp32 values of the frozen ones decoded from the codes).  Before the
+        first stage the mask is all ones (the values are never selected), so the effective weight has the same form
+        - where(mask, w, frozen) - in every stage, and a step captured before a stage stays valid after it.  Persistent
+        tensors (_refresh_frozen), refreshed after quantize_portion, state_dict loads, device moves and whenever the
+        buffers were written through torch."""
         key = (self.codes._version, self.mask._version, self.exponents._version, self.weight.device)
-        if getattr(self, "_cache", None) is None or self._cache[0] != key:
-            q = self.codebook()
-            self._cache = (key, self.mask.bool(), q[self.codes.clamp(max=q.numel() - 1).long()])
+        if self._cache is None or self._cache[0] != key:
+            self._refresh_frozen()
         return self._cache[1], self._cache[2]
 
     def effective_weight(self):

@@ -30,6 +30,23 @@ def split_parameters(model):
     return prim, qlev, rest
 
 
+class OptimizerSet(tuple):
+    """The optimizers of a model in the reference's step order (adp_qtz_fan.py:291-293), holding only the groups
+    that have parameters, each with its role: `roles[i]` in ("prim", "q", "rest") names what `self[i]` updates, and
+    `by_role("q")` returns that optimizer or None.  Code that needs the reference's three positions (checkpoints:
+    optimizer_prim / optimizer_q / optimizer) goes by role, not by index."""
+
+    ROLES = ("prim", "q", "rest")
+
+    def __new__(cls, pairs):
+        self = super().__new__(cls, [o for _, o in pairs])
+        self.roles = tuple(r for r, _ in pairs)
+        return self
+
+    def by_role(self, role):
+        return self[self.roles.index(role)] if role in self.roles else None
+
+
 def make_optimizers(model, config, capturable=False, fused=False):
     """fused=True selects torch's single-kernel multi-tensor Adam (same update rule, one pass over
     the 34 MB of p_c instead of about ten)."""
@@ -38,9 +55,10 @@ def make_optimizers(model, config, capturable=False, fused=False):
     if fused:
         kw["fused"] = True
     # q_level of the `fix` variant has requires_grad=False: Adam skips parameters without grad
-    groups = ((prim, getattr(config, "prim_lr", 1e-2)), (qlev, getattr(config, "q_lr", 1e-3)), (rest, getattr(config, "lr", 1e-2)))
+    groups = (("prim", prim, getattr(config, "prim_lr", 1e-2)), ("q", qlev, getattr(config, "q_lr", 1e-3)),
+              ("rest", rest, getattr(config, "lr", 1e-2)))
     # (models without adaptive layers, e.g. the ternary ones, have no p_c / q_level: only the groups that exist)
-    return tuple(torch.optim.Adam(g, lr=lr, **kw) for g, lr in groups if g)
+    return OptimizerSet([(role, torch.optim.Adam(g, lr=lr, **kw)) for role, g, lr in groups if g])
 
 
 class DataParallel:

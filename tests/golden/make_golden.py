@@ -584,10 +584,56 @@ def gen_baseline(torch):
     np.savez_compressed(os.path.join(OUT, "baseline.npz"), **out)
 
 
+def gen_data(torch):
+    """The reference's reader (adp_qtz_fan.py:452-503, `load_data`; the same text in fix / hint / baseline) run on a
+    synthetic directory in the CIFAR-10 python format: six pickled batch files with a uint8 (n, 3072) b"data" array and
+    a b"labels" list.  Batch sizes differ per file and data_batch_5 holds an odd number of images, so the split
+    `int(len / 2)` is exercised.  Stored: the raw batch contents (the test rebuilds the directory from them) and the
+    arrays the reference returns for "train" / "valid" / "test", plus the (image, label) pairs its CIFAR10Dataset
+    hands out without a transform (adp_qtz_fan.py:506-530)."""
+    import pickle
+    import tempfile
+    out = {}
+    rs = np.random.RandomState(77)
+    sizes = {"data_batch_1": 6, "data_batch_2": 4, "data_batch_3": 5, "data_batch_4": 3, "data_batch_5": 7, "test_batch": 5}
+    with tempfile.TemporaryDirectory() as d:
+        for name, n in sizes.items():
+            data = rs.randint(0, 256, (n, 3072)).astype(np.uint8)
+            labels = [int(v) for v in rs.randint(0, 10, n)]
+            with open(os.path.join(d, name), "wb") as f:
+                pickle.dump({b"batch_label": name.encode(), b"labels": labels, b"data": data,
+                             b"filenames": [b"img_%d.png" % i for i in range(n)]}, f)
+            out["raw_" + name + "_data"] = data
+            out["raw_" + name + "_labels"] = np.array(labels, np.int64)
+        for variant in ("fan", "fix", "hint", "baseline"):
+            mod = load_ref("adp_qtz_%s.py" % variant)
+            for split in ("train", "valid", "test"):
+                data, label = mod.load_data(d, split)
+                if variant == "fan":
+                    out[split + "_data"] = np.ascontiguousarray(data)
+                    out[split + "_label"] = np.asarray(label)
+                    out[split + "_dtype"] = np.array([str(data.dtype), str(np.asarray(label).dtype)])
+                else:  # the four scripts carry the same reader: one fixture serves all
+                    assert np.array_equal(out[split + "_data"], data) and np.array_equal(out[split + "_label"], label), variant
+            try:
+                mod.load_data(d, "nope")
+                raise AssertionError("reference accepted an unknown split")
+            except ValueError as e:
+                out["bad_split_message"] = np.array(str(e))
+        fan = load_ref("adp_qtz_fan.py")
+        ds = fan.CIFAR10Dataset(d, "valid", None)
+        out["dataset_len"] = np.int64(len(ds))
+        out["dataset_items"] = np.stack([np.asarray(ds[i][0]) for i in range(len(ds))])
+        out["dataset_labels"] = np.array([int(ds[i][1]) for i in range(len(ds))], np.int64)
+    out["names"] = np.array(list(sizes))
+    np.savez_compressed(os.path.join(OUT, "data.npz"), **out)
+    print("data.npz: train %s valid %s test %s" % (out["train_data"].shape, out["valid_data"].shape, out["test_data"].shape))
+
+
 def main():
     import torch
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block", "ckpt", "baseline"]
+    which = sys.argv[1:] or ["synth", "conv", "linear", "levels", "train", "block", "ckpt", "baseline", "data"]
     for w in which:
         globals()["gen_" + w](torch)
 

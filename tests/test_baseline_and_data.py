@@ -47,6 +47,29 @@ def test_cifar_reader_split_and_layout(tmp_path):
         D.load_data(str(tmp_path), "nope")
 
 
+def test_cifar_reader_equals_the_reference_reader(tmp_path):
+    """data.load_data against the arrays the reference's own load_data (adp_qtz_fan.py:458-503; the same reader in fix /
+    hint / baseline) returned for the same batch files (tests/golden/data.npz, written by make_golden.py gen_data): split
+    with an odd data_batch_5, image layout, label order, and the items CIFAR10Dataset hands out (adp_qtz_fan.py:516-526)."""
+    from quantized_cnn_amd import data as D
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data.npz"))
+    for name in g["names"]:
+        with open(str(tmp_path / str(name)), "wb") as f:
+            pickle.dump({b"batch_label": str(name).encode(), b"labels": [int(v) for v in g["raw_%s_labels" % name]],
+                         b"data": g["raw_%s_data" % name], b"filenames": []}, f)
+    for split in ("train", "valid", "test"):
+        data, label = D.load_data(str(tmp_path), split)
+        assert data.dtype == np.uint8 and str(g[split + "_dtype"][0]) == "uint8"
+        assert np.array_equal(data, g[split + "_data"]), split
+        assert np.array_equal(label, g[split + "_label"]), split
+    assert len(D.load_data(str(tmp_path), "train")[0]) == 6 + 4 + 5 + 3 + 3 and len(D.load_data(str(tmp_path), "valid")[0]) == 4
+    with pytest.raises(ValueError) as e:
+        D.load_data(str(tmp_path), "nope")
+    assert str(e.value) == str(g["bad_split_message"])
+    va, lva = D.load_data(str(tmp_path), "valid")  # what the reference's Dataset indexes: image i, label i
+    assert len(va) == int(g["dataset_len"]) and np.array_equal(va, g["dataset_items"]) and np.array_equal(lva, g["dataset_labels"])
+
+
 def test_batch_files_cannot_smuggle_code(tmp_path):
     from quantized_cnn_amd import data as D
 
@@ -59,7 +82,9 @@ def test_batch_files_cannot_smuggle_code(tmp_path):
         D.unpickle(str(tmp_path / "x"))
 
 
-def test_oracle_augment_known_answers():
+def test_oracle_augment_known_answers_parity_unpinned_torchvision_absent():
+    """The transforms (adp_qtz_fan.py:164-174) are torchvision's, which is not installed: the numpy restatement is checked
+    against hand-computed answers only - parity unpinned."""
     data = np.arange(2 * 4 * 4 * 3, dtype=np.uint8).reshape(2, 4, 4, 3)
     mean, std = (0.5, 0.25, 0.0), (0.5, 1.0, 2.0)
     out = O.augment_batch(data, [1, 0], [1, 0], [1, 2], [0, 1], pad=1, mean=mean, std=std)
@@ -77,7 +102,7 @@ def test_oracle_augment_known_answers():
 # ------------------------------------------------------------------------------------ GPU
 
 @pytest.mark.gpu
-def test_augment_kernel_bit_exact_vs_oracle():
+def test_augment_kernel_bit_exact_vs_oracle_parity_unpinned_torchvision_absent():
     import quantized_cnn_amd.ops as ops
     rs = np.random.RandomState(3)
     data = rs.randint(0, 256, (50, 32, 32, 3)).astype(np.uint8)

@@ -322,3 +322,91 @@ def test_inq_layer_survives_a_state_dict_round_trip():
     assert float(b.weight.grad[b.mask == 0].abs().max()) == 0.0
     b.quantize_portion(0.75)
     assert abs(1.0 - float(b.mask.float().mean()) - 0.75) <= 1e-3 and torch.equal(a.exponents, b.exponents)
+
+
+def test_captured_step_follows_inq_stages():
+    """A step captured as one HIP graph BEFORE an INQ stage must train on the new partition after
+    quantize_portion(): the boolean masks and decoded frozen values the graph reads are persistent tensors that
+    the stage rewrites in place.  The same schedule run eagerly from the same start gives the same parameters
+    bit for bit (same kernels, same order)."""
+    from quantized_cnn_amd.train import CapturedStep
+    c = argparse.Namespace(mode_q="inq")
+    g = torch.Generator(device=DEV).manual_seed(7)
+    xs = [torch.randn(8, 3, 32, 32, device=DEV, generator=g) for _ in range(6)]
+    ys = [torch.randint(0, 10, (8,), device=DEV, generator=g) for _ in range(6)]
+
+    def fresh():
+        torch.manual_seed(2)
+        model = T.ResNet(c, 1).to(DEV).train()
+        return model, torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9), [m for m in model.modules() if isinstance(m, T.INQConv2d)]
+
+    def eager_step(model, opt, x, y):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    schedule = [(None, 0), (None, 1), (0.5, 2), (None, 3), (0.75, 4), (1.0, 5)]  # (stage before the step, batch)
+    m1, o1, c1 = fresh()
+    eager = [eager_step(m1, o1, xs[0], ys[0])]  # the captured step's warm-up step
+    for frac, i in schedule:
+        if frac is not None:
+            for m in c1:
+                m.quantize_portion(frac)
+        eager.append(eager_step(m1, o1, xs[i], ys[i]))
+    m2, o2, c2 = fresh()
+    step = CapturedStep(m2, o2, torch.nn.functional.cross_entropy, warmup=1)
+    graph = []
+    for frac, i in schedule:
+        if frac is not None:
+            for m in c2:
+                m.quantize_portion(frac)
+        graph.append(float(step(xs[i], ys[i])))
+    assert graph == eager[1:]
+    for (n, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), n
+    for m in c2:  # every weight frozen at a power of two (or zero), whatever momentum did to the parameter
+        w = m.effective_weight().detach().abs()
+        nz = w[w > 0]
+        assert int(m.mask.sum()) == 0 and torch.equal(torch.log2(nz), torch.log2(nz).round())
+    # a state_dict load into the captured model is seen by the next replay as well
+    sd = {k: v.clone() for k, v in m1.state_dict().items()}
+    l_e = eager_step(m1, o1, xs[0], ys[0])
+    m2.load_state_dict(sd)
+    assert float(step(xs[0], ys[0])) == l_e
+
+
+@pytest.mark.parametrize("mode_q", ["ttq", "inq"])
+def test_checkpoint_round_trip_of_models_without_adaptive_layers(mode_q, tmp_path):
+    """Ternary / INQ models have no p_c / q_level, so train.make_optimizers holds one optimizer ("rest"); the
+    checkpoint keeps the reference's eight keys (adp_qtz_fan.py:331-340) with empty entries for the absent groups and
+    restores the one optimizer from the entry of its role."""
+    from quantized_cnn_amd import checkpoint as ck
+    from quantized_cnn_amd.train import TrainStep
+    c = argparse.Namespace(mode_q=mode_q, l2_reg=5e-4, lr=1e-3)
+    torch.manual_seed(3)
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+    model = T.ResNet(c, 1).to(DEV).train()
+    if mode_q == "inq":
+        for m in model.modules():
+            if isinstance(m, T.INQConv2d):
+                m.quantize_portion(0.5)
+    step = TrainStep(model, c, T)
+    assert step.opts.roles == ("rest",) and step.opts.by_role("prim") is None
+    for _ in range(2):
+        step(x, y)
+    path = str(tmp_path / "ck.pth")
+    ck.save_checkpoint(path, model, step.opts, 1, 3, 17, 0.25)
+    res = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(res) == set(ck.CHECKPOINT_KEYS) and res["optimizer_prim"]["param_groups"] == [] and res["optimizer"]["param_groups"]
+    after = float(step(x, y))
+    model2 = T.ResNet(c, 1).to(DEV).train()
+    step2 = TrainStep(model2, c, T)
+    assert ck.load_checkpoint(path, model2, step2.opts) == (1, 3, 17, 0.25)
+    assert float(step2(x, y)) == after
+    for (n, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), n
+    with pytest.raises(ValueError):
+        ck.save_checkpoint(path, model, [step.opts[0]], 1, 0, 0, 0.0)  # a bare list that is not the reference's three
