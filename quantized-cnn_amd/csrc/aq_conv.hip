@@ -29,20 +29,6 @@
 
 namespace aq {
 
-#ifdef AQ_EXPERIMENT
-// experiment builds: per-phase timestamps (100 MHz wall clock) of three workgroups (first, middle, last)
-// and two threads each (0 and 256), 16 slots per (workgroup, thread)
-__device__ long long aq_trace[3 * 2 * 16];
-#define AQ_STAMP(i)                                                                                          \
-    do {                                                                                                     \
-        if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.z == 0) {                \
-            const int w_ = blockIdx.x == 0 ? 0 : ((blockIdx.x == gridDim.x / 2) ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1)); \
-            if (w_ >= 0) aq_trace[(w_ * 2 + (threadIdx.x >> 8)) * 16 + (i)] = wall_clock64();                \
-        }                                                                                                    \
-    } while (0)
-#else
-#define AQ_STAMP(i) do { } while (0)
-#endif
 
 // Fill the LDS image xs[nch][plane] of one input tile: plane = rows_in x pitch elements starting at
 // (r0, c0) in (dilated) input coordinates, zero outside the tensor.  Lanes own plane elements
@@ -512,7 +498,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jn = lane & 15, kq = lane >> 4;
     const int m0 = bc.y * 16 * MT;
-    AQ_STAMP(0);
 
     const bool par = MODE == MODE_DGRAD && a.par != 0;
     for (int k = tid; k < a.Kpad; k += 256) {
@@ -583,9 +568,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             off[j] = ok ? (unsigned)(gy * a.IW + gxj[j]) * 4u : BUF_OOB;
             inmask = j == 0 ? (unsigned)ok : (inmask | ((unsigned)ok << j));
         }
-#ifdef AQ_EXPERIMENT
-        if (a.dbg & 2) return;
-#endif
 #pragma unroll
         for (int u = 0; u < CH4; ++u) {
             // channels beyond KC are never committed: clamp so that the scalar offset stays inside the tensor
@@ -612,7 +594,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
     // the first tile's loads are issued before the weight panel's, so both are in flight together
     int tile = bc.x;
     if (tile < ntiles) fetch_tile(tile);
-    AQ_STAMP(1);
 
     // weight panel in fragment order: element (row rl, k) lives at
     //   As[(((k>>4)*MT + (rl>>4))*64 + ((k>>2)&3)*16 + (rl&15))*4 + (k&3)]
@@ -724,7 +705,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             bsh[u] = sh[u];
         }
     }
-    AQ_STAMP(7);
 
     // k-blocks a tile walks: all of them, or (parity classes) the share of the tile's class; set per tile
     int kb_lo = 0, nkb = a.Kpad >> 4;
@@ -767,12 +747,10 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             }
     }
 
-    AQ_STAMP(2);
     int tcount_ = 0;
     for (; tile < ntiles; tile += bc.gx) {
         commit_tile();
         __syncthreads();  // image (and, the first time, tables and weight panel) visible
-        if (tcount_ == 0) AQ_STAMP(3);
         const int next = tile + bc.gx;
         if (next < ntiles) fetch_tile(next);  // in flight during the MFMAs below
         // the epilogue's second operand (the shortcut added to the output, or the batch-norm input whose
@@ -831,11 +809,7 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
         load_k(1, kofB);
         load_a(0, av0);
         load_b(kofA, bv0);
-#ifdef AQ_EXPERIMENT
-        const int nkb_run = (a.dbg & 1) ? 0 : nkb;
-#else
         const int nkb_run = nkb;
-#endif
         for (int kb = 0; kb < nkb_run; kb += 2) {
             // sched_barrier: keep each group of LDS reads ahead of the other set's MFMAs (the
             // scheduler otherwise sinks the reads next to their consumers and the wave stalls)
@@ -852,15 +826,11 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             mfmas(av1, bv1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (tcount_ == 0) AQ_STAMP(4);
         const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + img, (unsigned)(a.M * ohw) * 4u);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int oy = (oy0 + (pyx[nt] >> 16)) * os + cpy, ox = (pyx[nt] & 0xffff) * os + cpx;
             const bool pok = pyx[nt] >= 0 && oy < a.OH;
-#ifdef AQ_EXPERIMENT
-            if (a.dbg & 4) continue;
-#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -883,7 +853,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
                 }
         }
         __syncthreads();  // every wavefront is done with this tile's LDS image
-        if (tcount_ == 0) AQ_STAMP(5);
         ++tcount_;
     }
     if (stats_on || bnb_on) {
@@ -918,7 +887,6 @@ __device__ __forceinline__ void conv_gemm_persist_body(const ConvArgs &a, const 
             }
         }
     }
-    AQ_STAMP(6);
 }
 
 template <int MT, int NT, int CH4, int J, int MODE>
@@ -966,7 +934,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const bool loader = threadIdx.x >= 256;
     const int jn = lane & 15, kq = lane >> 4;
-    AQ_STAMP(0);
 
     int bx = bc.x;
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
@@ -1217,7 +1184,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
         if (nch > 0) fetch_chunk(0, svA, dvA);
         if (DEEP && nch > 1) fetch_chunk(1, svB, dvB);
     }
-    AQ_STAMP(1);
     if constexpr (DEEP) {
         for (int im = 0; im <= nch; im += 2) {
             if (loader) {
@@ -1226,7 +1192,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
             } else if (im >= 1) {
                 compute_chunk(im - 1);
             }
-            AQ_STAMP(2 + (im < 9 ? im : 9));  // before the barrier: own work of phase im done
             __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
             if (im + 1 > nch) break;
             if (loader) {
@@ -1235,7 +1200,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
             } else {
                 compute_chunk(im);
             }
-            AQ_STAMP(2 + (im + 1 < 9 ? im + 1 : 9));
             __syncthreads();
         }
     } else {
@@ -1250,11 +1214,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
             } else if (im >= 1) {
                 compute_chunk(im - 1);
             }
-            AQ_STAMP(2 + (im < 9 ? im : 9));
             __syncthreads();  // buffer (im & 1) filled, buffer ((im-1) & 1) consumed
         }
     }
-    AQ_STAMP(12);
 
     // ---- sum the 4 compute wavefronts in LDS (fixed order 0+1+2+3), write the workgroup's slab ------
     float *part = a.part + (long long)bc.x * a.Cout * a.K9;
@@ -1294,7 +1256,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs &a, const BlockC
             }
         }
     }
-    AQ_STAMP(13);
 }
 
 template <int MG, int NG, int CH4, int J>
@@ -1720,9 +1681,6 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
     a.plane = a.rows_in * a.pitch;
     a.Kpad = (a.K + 31) & ~31;  // even number of 16-wide k-blocks (main loops are unrolled by two)
     a.vecA = (a.K % 4 == 0) && (((uintptr_t)a.W & 15) == 0);
-#ifdef AQ_EXPERIMENT
-    if (const char *e = getenv("AQ_CONV_DBG")) a.dbg = atoi(e);
-#endif
     size_t lds = (size_t)a.Kpad * 4 * (MODE == MODE_DGRAD ? 2 : 1) + (MODE == MODE_FWD_CODES ? ((a.L + 3) & ~3) * 4 : 0) +
                  (size_t)a.KC * a.plane * 4;
     const long long gx = (long long)N * a.tiles_x * a.tiles_y;
@@ -1862,12 +1820,6 @@ static int conv_fwd_common(const float *x, const float *W, const uint8_t *idx, c
 
 extern "C" {
 
-#ifdef AQ_EXPERIMENT
-int aq_debug_read_trace(long long *host_out)
-{
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(aq::aq_trace), sizeof(long long) * 96);
-}
-#endif
 
 int aq_conv_fwd(const float *x, const float *W, float *y, int N, int Cin, int H, int Wd, int Cout, int ksize, int stride, int pad, void *stream)
 {

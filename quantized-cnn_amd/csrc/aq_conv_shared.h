@@ -70,7 +70,6 @@ struct ConvArgs {
     // fma(bx, scale, shift) > 0 else 0, xhat = (bx - mean) * rstd, into bwd_part[M][gridDim.x] (NULL: off)
     const float *bx, *bgamma, *bbeta, *bmean, *brstd;
     float2 *bwd_part;
-    int dbg;             // experiment builds only: 1 = skip MFMA loop, 2 = skip input loads, 4 = skip stores
     // general kernel (conv_gemm_chunked_kernel) only: kernel size, taps per channel, rows / columns of padding in
     // front of the (dilated) input, channels per LDS chunk, k extent of a chunk padded to whole k-blocks
     int ks, ks2, padT, CK, Kc;

@@ -607,9 +607,6 @@ static inline int lanes_for(int L) { return L <= 32 ? 8 : (L <= 64 ? 16 : 32); }
 // shorter-lived wavefronts overlap better than long ones (measured: 5.7 TB/s at 1, 4.7 TB/s at 16).
 static inline int choose_K(long long total_rows)
 {
-#ifdef AQ_EXPERIMENT
-    if (const char *e = getenv("AQ_SYNTH_K")) return atoi(e);
-#endif
     (void)total_rows;
     return 1;
 }
@@ -760,9 +757,6 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
     // gradient +3-5 %, gradient with Adam +4-12 % on 50 M .. 1 B coefficients.  (A training step's 19 layers, 0.27 M rows,
     // measured no faster and keep 64 rows; so do ragged rows: 5.24 against 5.41 TB/s in the gradient at L = 31.)
     int half_mask = 7;  // 1 forward, 2 gradient, 4 gradient with Adam
-#ifdef AQ_EXPERIMENT
-    if (const char *e = getenv("AQ_SYNTH_HALF")) half_mask = atoi(e);
-#endif
     long long call_rows = 0;
     for (int i = 0; i < nseg; ++i) call_rows += segs[i].rows;
     const bool half_call = stream_policy && !exact && call_rows >= (1LL << 19) &&

@@ -3,7 +3,8 @@ model and no ternary / INQ quantiser: parity unpinned).  With INQ layers before 
 plain fp32 ResNet-18, so loss and every gradient can be checked against the same network written with stock torch
 operators; the quantised modes are checked for what the papers prescribe (ternary codes, frozen powers of two) and for
 a training step that learns.  Inputs are 64 x 64 so that the file runs in seconds; the layer shapes at 224 x 224 are
-covered kernel by kernel in test_gpu_conv_general.py."""
+covered kernel by kernel in test_gpu_conv_general.py, and the whole model at 224 x 224 (batch 4) by the first test
+below and by the half-frozen INQ step."""
 import argparse
 
 import pytest
@@ -37,15 +38,54 @@ def stock_forward(model, x):
     return model.fc(torch.flatten(F.adaptive_avg_pool2d(out, 1), 1))
 
 
-def test_unfrozen_inq_resnet18_equals_the_stock_network():
+def _float64_reference(model, x, y, weights=None):
+    """Loss and gradients of the same network through torch's own operators in float64 on the host (weights: optional
+    {conv module name: tensor} replacing convolution weights, e.g. an INQ layer's effective weights)."""
+    import copy
+    ref = copy.deepcopy(model).cpu().double()
+    if weights:
+        mods = dict(ref.named_modules())
+        for n, w in weights.items():
+            mods[n].weight.data.copy_(w.detach().cpu().double())
+    ref.zero_grad(set_to_none=True)
+    loss = F.cross_entropy(stock_forward(ref, x.cpu().double()), y.cpu())
+    loss.backward()
+    return float(loss.detach()), {n: p.grad for n, p in ref.named_parameters()}
+
+
+def _near_float64(got, want, name):
+    """Gradient of one tensor against the float64 evaluation at 224 x 224: relative L2 error <= 2e-2 and largest
+    deviation <= 0.1 of the largest entry.  This is as tight as any fp32 evaluation of this network can be held: with
+    ~2e7 activations some ReLU / max-pool inputs lie within rounding of a decision boundary, a decision taken the other
+    way in a 14 x 14 or 7 x 7 layer moves a per-channel sum over 4 * 196 terms by 1e-3 .. 1e-2 of itself, and every layer
+    upstream inherits it.  Measured against float64 (batch 4 and 16): this library L2 3.8e-3 median / 6.0e-3 worst,
+    largest deviation 4.7e-2 .. 6.8e-2; torch's own fp32 operators on the same GPU 2.0e-3 / 3.6e-3 and 4.2e-2.  A wiring
+    error (a wrong tap, stride, halo or shortcut at one of the 224-sized shapes) shows as O(1)."""
+    d = got.detach().cpu().double() - want
+    l2 = float(d.norm()) / max(float(want.norm()), 1e-300)
+    mx = float(d.abs().max()) / max(float(want.abs().max()), 1e-300)
+    assert l2 <= 2e-2 and mx <= 0.1, (name, l2, mx)
+
+
+@pytest.mark.parametrize("size", [64, 224])
+def test_unfrozen_inq_resnet18_equals_the_stock_network(size):
+    """size 224: the input size BASELINE's INQ ResNet-18 configuration names (every layer at its stated shape, batch 4).
+    Checked against the stock operators on the GPU (fp32, other summation order) and, at 224, against a float64
+    evaluation on the host, which is what both fp32 results approximate."""
     torch.manual_seed(0)
     model = ResNet18(config("inq"), num_classes=10).to(DEV).train()
-    x = torch.randn(4, 3, 64, 64, device=DEV)
+    x = torch.randn(4, 3, size, size, device=DEV)
     y = torch.randint(0, 10, (4,), device=DEV)
     loss = F.cross_entropy(model(x), y)
     loss.backward()
     got = {n: p.grad.clone() for n, p in model.named_parameters()}
     model.zero_grad(set_to_none=True)
+    if size == 224:
+        l64, g64 = _float64_reference(model, x, y)
+        assert abs(float(loss.detach()) - l64) <= 1e-5 * abs(l64)
+        for n, p in model.named_parameters():
+            _near_float64(got[n], g64[n], n)
+        return
     ref = F.cross_entropy(stock_forward(model, x), y)
     ref.backward()
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
@@ -86,6 +126,31 @@ def test_resnet18_training_step_learns_in_every_quantiser_mode(mode_q):
                 nz = fz[fz > 0]
                 assert torch.equal(torch.log2(nz), torch.log2(nz).round())
                 assert float(m.weight.grad[m.mask == 0].abs().max()) == 0.0
+
+
+def test_half_frozen_inq_resnet18_at_224_equals_the_stock_network_on_its_effective_weights():
+    """INQ at its first stage (half of every layer frozen at powers of two), 224 x 224, batch 4: loss and the gradients
+    of the trainable coordinates equal those of the stock network evaluated on the effective weights; frozen
+    coordinates receive exactly zero."""
+    torch.manual_seed(3)
+    model = ResNet18(config("inq"), num_classes=10).to(DEV).train()
+    convs = [(n, m) for n, m in model.named_modules() if isinstance(m, T.INQConv2d)]
+    assert len(convs) == 19
+    for _, m in convs:
+        m.quantize_portion(0.5)
+    x = torch.randn(4, 3, 224, 224, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    loss = F.cross_entropy(model(x), y)
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters()}
+    l64, g64 = _float64_reference(model, x, y, {n: m.effective_weight() for n, m in convs})
+    assert abs(float(loss.detach()) - l64) <= 1e-5 * abs(l64)
+    masks = {n + ".weight": m.mask.bool().cpu() for n, m in convs}
+    for n, p in model.named_parameters():
+        want = g64[n] if n not in masks else torch.where(masks[n], g64[n], torch.zeros_like(g64[n]))
+        _near_float64(got[n], want, n)
+        if n in masks:
+            assert float(got[n].cpu()[~masks[n]].abs().max()) == 0.0, n
 
 
 def test_resnet18_step_as_one_graph_equals_eager_steps():
