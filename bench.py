@@ -218,72 +218,121 @@ def kernel_rooflines(quick):
     return roof, more
 
 
-def ternary_step(steps=100, warmup=20):
-    """BASELINE configs[1] read literally: the ResNet-20 graph with TTQ convolutions (learned Wp / Wn; the papers'
-    quantiser, no reference implementation: parity unpinned), batch 128, same step shape as the headline workload
-    (forward, cross entropy + l2, backward, Adam), replayed as one HIP graph."""
-    import quantized_cnn_amd.ternary as ternary
-    from quantized_cnn_amd.train import TrainStep, make_optimizers
-    out = {}
-    for mode in ("ttq", "twn"):
-        c = cfg()
-        c.mode_q = mode
-        torch.manual_seed(0)
-        model = ternary.ResNet(c, 3).cuda().train()
-        step = TrainStep(model, c, ternary, use_graph=True)
-        step.opts = make_optimizers(model, c, capturable=True, fused=True)  # torch's fused Adam kernels inside the graph
-        g = torch.Generator(device="cuda").manual_seed(1000)
-        x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
-        y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
-        for _ in range(warmup):
-            step(x, y)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step(x, y)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        out[mode] = {"value": round(BATCH / dt, 1), "unit": "img/s", "ms_per_step": round(dt * 1e3, 4), "final_loss": round(float(loss), 5)}
-    out["workload"] = ("ResNet-20 with ternary convolutions (quantized_cnn_amd.ternary.ResNet: TTQ learned Wp / Wn, TWN), batch %d, synthetic "
-                       "CIFAR-10, TrainStep(use_graph=True) with torch's fused Adam: fwd + CE + l2 + bwd + Adam in one HIP graph" % BATCH)
-    out["parity"] = "unpinned (no reference implementation)"
-    return out
-
-
-def inq_resnet18(steps=20, warmup=5, batch=32):
-    """BASELINE configs[2] read literally: ResNet-18 at 224 x 224 with INQ convolutions (5-bit powers of two, half of the
-    weights frozen), synthetic data, batch 32 per GPU: forward, cross entropy, backward, SGD with momentum as one HIP graph
-    (train.CapturedStep).  No reference model or INQ implementation exists: parity unpinned."""
-    from quantized_cnn_amd.resnet18 import ResNet18
-    from quantized_cnn_amd.train import CapturedStep
-    import quantized_cnn_amd.adp_qtz_fan as fan
+def build_workload(name, rank, dp_factory, args):
+    """-> dict(step, x, y, batch, workload, parity, model).  name:
+         adaptive      the reference's model: ResNet-20 with adp_qtz_fan layers (32 learned levels, soft assignment), batch 128
+         ttq_resnet20  BASELINE configs[1] read literally: the same graph with TTQ convolutions (learned Wp / Wn), batch 128
+         twn_resnet20  the same with TWN convolutions
+         inq_resnet18  BASELINE configs[2] read literally: ResNet-18 at 224 x 224, INQ 5-bit powers of two, half frozen, batch 32
+    The last three have no reference implementation (parity unpinned)."""
+    from quantized_cnn_amd.train import FusedTernaryStep, FusedTrainStep
     c = cfg()
-    c.mode_q = "inq"
     torch.manual_seed(0)
-    model = ResNet18(c, fan).cuda().train()
-    for m in model.modules():
-        if hasattr(m, "quantize_portion"):
-            m.quantize_portion(0.5)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
-    step = CapturedStep(model, opt, torch.nn.functional.cross_entropy)
-    g = torch.Generator(device="cuda").manual_seed(1000)
-    x = torch.randn(batch, 3, 224, 224, device="cuda", generator=g)
-    y = torch.randint(0, 1000, (batch,), device="cuda", generator=g)
+    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    if name == "adaptive":
+        import quantized_cnn_amd.adp_qtz_fan as fan
+        fan.beta = 1
+        model = fan.ResNet(c, 3).cuda().train()
+        dp = dp_factory(model)
+        step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None,
+                              overlap_wgrad=args.overlap_wgrad)
+        batch, size, classes = BATCH, 32, 10
+        desc = ("quantized ResNet-20 as the reference implements it (adp_qtz_fan: 19 layers x 32 learned levels, soft assignment) on synthetic "
+                "CIFAR-10 32x32, full step fwd+CE+model_loss+bwd+3xAdam (train.FusedTrainStep)")
+        parity = "pinned to the reference (tests/golden)"
+    elif name in ("ttq_resnet20", "twn_resnet20"):
+        import quantized_cnn_amd.ternary as ternary
+        c.mode_q = name[:3]
+        model = ternary.ResNet(c, 3).cuda().train()
+        dp = dp_factory(model)
+        step = FusedTernaryStep(model, c, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None)
+        batch, size, classes = BATCH, 32, 10
+        desc = ("BASELINE configs[1] read literally: ResNet-20 with %s convolutions (quantized_cnn_amd.ternary.ResNet%s; threshold 0.7 * mean|w|) on "
+                "synthetic CIFAR-10 32x32, full step fwd+CE+l2+bwd+Adam (train.FusedTernaryStep)"
+                % (name[:3].upper(), ", learned Wp / Wn" if name.startswith("ttq") else ""))
+        parity = "unpinned (no reference implementation)"
+    elif name == "inq_resnet18":
+        from quantized_cnn_amd.resnet18 import ResNet18
+        c.mode_q = "inq"
+        c.lr = 1e-3
+        model = ResNet18(c).cuda().train()
+        for m in model.modules():
+            if hasattr(m, "quantize_portion"):
+                m.quantize_portion(0.5)
+        dp = dp_factory(model)
+        step = FusedTernaryStep(model, c, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None)
+        batch, size, classes = 32, 224, 1000
+        desc = ("BASELINE configs[2] read literally: ResNet-18 at 224x224 with INQ convolutions (5-bit powers of two, 50 % frozen) on synthetic "
+                "ImageNet-shaped data, full step fwd+CE+l2+bwd+Adam (train.FusedTernaryStep), gradient exchange in 8 MiB buckets")
+        parity = "unpinned (no reference model or INQ implementation)"
+    else:
+        raise SystemExit("bench.py: unknown workload %r" % name)
+    x = torch.randn(batch, 3, size, size, device="cuda", generator=g)
+    y = torch.randint(0, classes, (batch,), device="cuda", generator=g)
+    return dict(step=step, x=x, y=y, batch=batch, workload=desc, parity=parity, model=model, dp=dp)
+
+
+def time_workload(w, steps, warmup, dist=None):
+    """W untimed steps, then exactly K timed steps between barriers + device synchronisation; -> (seconds, last loss)."""
+    step, x, y = w["step"], w["x"], w["y"]
+    step(x, y)
+    bufs = step.static_inputs()
+    if bufs is not None:  # the batch lives in the buffers the captured step reads (as a device-side loader leaves it)
+        bufs[0].copy_(x)
+        bufs[1].copy_(y)
+        x, y = bufs
     for _ in range(warmup):
         step(x, y)
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step(x, y)
+        step(x, y)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    del model, opt, step
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0, float(step.loss)
+
+
+def side_workload(name, steps, warmup, args):
+    """One of the other workloads, timed on this GPU beside the headline (no exchange)."""
+    w = build_workload(name, 0, lambda m: None, argparse.Namespace(no_graph=args.no_graph, force_exchange=False, overlap_wgrad=False))
+    dt, loss = time_workload(w, steps, warmup)
+    dt /= steps
+    out = {"value": round(w["batch"] / dt, 1), "unit": "img/s", "ms_per_step": round(dt * 1e3, 4), "final_loss": round(loss, 5),
+           "per_gpu_batch": w["batch"], "workload": w["workload"], "parity": w["parity"]}
+    if name == "inq_resnet18":
+        out["conv_tflops"] = round(3 * conv_flops_per_image(w["model"], 224) * w["batch"] / dt / 1e12, 1)
+    del w
     torch.cuda.empty_cache()
-    return {"value": round(batch / dt, 1), "unit": "img/s", "ms_per_step": round(dt * 1e3, 3), "final_loss": round(float(loss), 5),
-            "conv_tflops": round(3 * 1.8e9 * batch / dt / 1e12, 1),
-            "workload": "ResNet-18 @224 with INQ convolutions (5 bits, 50 %% frozen), batch %d, synthetic ImageNet-shaped data, "
-                        "train.CapturedStep: fwd + CE + bwd + SGD(momentum) in one HIP graph" % batch,
-            "parity": "unpinned (no reference implementation)"}
+    return out
+
+
+def conv_flops_per_image(model, size):
+    """Forward multiply-add flops (2 per MAC) of the model's convolutions for one size x size image, from the modules'
+    own shapes (a forward hook on every convolution-like module records its output plane)."""
+    total = [0]
+    hooks = []
+
+    def hook(m, inp, out):
+        o = out[0] if isinstance(out, tuple) else out
+        w = m.weight
+        total[0] += 2 * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * o.shape[2] * o.shape[3]
+    for m in model.modules():
+        w = getattr(m, "weight", None)
+        if w is not None and w.dim() == 4 and not isinstance(m, torch.nn.Conv2d):
+            hooks.append(m.register_forward_hook(hook))
+    c0 = model.conv0
+    with torch.no_grad():
+        was = model.training
+        model.eval()
+        model(torch.zeros(1, 3, size, size, device="cuda"))
+        model.train(was)
+    for h in hooks:
+        h.remove()
+    ho = (size + 2 * c0.padding[0] - c0.kernel_size[0]) // c0.stride[0] + 1
+    return total[0] + 2 * c0.weight.numel() * ho * ho
 
 
 def cpu_baseline(quick):
@@ -356,6 +405,8 @@ def main():
     ap.add_argument("--quick", action="store_true", help="smaller roofline tensor and CPU sample (development)")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline and cpu_baseline measurements")
     ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient groups on a second stream beside the rest of the backward pass")
+    ap.add_argument("--workload", default="adaptive", choices=("adaptive", "ttq_resnet20", "twn_resnet20", "inq_resnet18"),
+                    help="what the timed loop (value, ms_per_step, --gpus N) runs; the others are reported beside it on one GPU")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU form of the step (two HIP graphs around an RCCL all-reduce) even on one GPU")
     args = ap.parse_args()
@@ -377,40 +428,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    import quantized_cnn_amd.adp_qtz_fan as fan
-    from quantized_cnn_amd.train import DataParallel, FusedTrainStep
+    from quantized_cnn_amd.train import DataParallel
 
-    c = cfg()
-    fan.beta = 1
-    torch.manual_seed(0)
-    model = fan.ResNet(c, 3).cuda()
-    model.train()
-    dp = DataParallel(model) if dist is not None else None
-    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
-    x = torch.randn(BATCH, 3, 32, 32, device="cuda", generator=g)
-    y = torch.randint(0, 10, (BATCH,), device="cuda", generator=g)
-    step = FusedTrainStep(model, c, fan, dp=dp, use_graph=not args.no_graph, force_exchange=args.force_exchange and dp is not None,
-                          overlap_wgrad=args.overlap_wgrad)
-
-    step(x, y)
-    bufs = step.static_inputs()
-    if bufs is not None:  # the batch lives in the buffers the captured step reads (as a device-side loader leaves it)
-        bufs[0].copy_(x)
-        bufs[1].copy_(y)
-        x, y = bufs
-    for _ in range(args.warmup):
-        step(x, y)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(x, y)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    loss = float(step.loss)
+    w = build_workload(args.workload, rank, (lambda m: DataParallel(m)) if dist is not None else (lambda m: None), args)
+    dp = w["dp"]
+    batch = w["batch"]
+    elapsed, loss = time_workload(w, args.steps, args.warmup, dist)
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,21 +442,26 @@ def main():
     if rank == 0:
         out = {
             "metric": "train img/s (quantized ResNet-20, synthetic CIFAR-10) + quantize-kernel HBM GB/s vs peak",
-            "value": round(world * BATCH * args.steps / elapsed, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * batch * args.steps / elapsed, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: quantized ResNet-20 (adp_qtz_fan: 19 layers x 32 learned levels, soft "
-                                   "assignment) on synthetic CIFAR-10 32x32, full step fwd+CE+model_loss+bwd+3xAdam",
-                       "global_batch": world * BATCH, "per_gpu_batch": BATCH, "parallelism": "dp%d" % world,
-                       "hip_graphs": not args.no_graph, "exchange": "rccl all-reduce of the flat dW buffer" if dp is not None else "none"},
+            "config": {"workload": w["workload"], "workload_name": args.workload, "parity": w["parity"],
+                       "global_batch": world * batch, "per_gpu_batch": batch, "parallelism": "dp%d" % world,
+                       "hip_graphs": not args.no_graph,
+                       "exchange": ("none" if dp is None else "rccl all-reduce of the flat gradient buffer" +
+                                    (" in %d MiB buckets" % (w["step"].bucket_bytes >> 20) if hasattr(w["step"], "bucket_bytes") else ""))},
             "final_loss": round(loss, 5),
         }
         if not args.skip_extras:
             roof, more = kernel_rooflines(args.quick)
             out["roofline"] = roof
             out["roofline_more"] = more
-            out["ternary_resnet20"] = ternary_step(20 if args.quick else 100, 5 if args.quick else 20)
-            out["inq_resnet18"] = inq_resnet18(5 if args.quick else 20, 2 if args.quick else 5)
+            del w
+            torch.cuda.empty_cache()
+            # the other workloads on this GPU: second top-level values, each with its own workload text
+            for name, k, wu in (("adaptive", 100, 20), ("ttq_resnet20", 100, 20), ("twn_resnet20", 100, 20), ("inq_resnet18", 20, 5)):
+                if name != args.workload:
+                    out[name] = side_workload(name, 20 if args.quick and k > 20 else (5 if args.quick else k), 2 if args.quick else wu, args)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.quick)
         print(json.dumps(out), flush=True)

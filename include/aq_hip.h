@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 11
+#define AQ_ABI_VERSION 12
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -378,6 +378,12 @@ typedef struct aq_tern_seg {
     const float *dWt;     /* [n] d loss / d w~                                                             */
     float *dW;            /* [n] d loss / d w (latent)                                                     */
     float *dWp, *dWn;     /* [1] TTQ: d loss / d Wp, d loss / d Wn                                          */
+    /* aq_inq_effective */
+    const float *frozen;  /* [n] INQ: decoded values of the frozen weights (read where mask == 0)          */
+    /* aq_tern_bwd_adam: torch.optim.Adam state (exp_avg, exp_avg_sq, one-element step) of W and of the TTQ scales */
+    float *adam_m, *adam_v, *adam_step;
+    float *Wp_m, *Wp_v, *Wp_step;
+    float *Wn_m, *Wn_v, *Wn_step;
 } aq_tern_seg;
 size_t aq_tern_workspace_bytes(const aq_tern_seg *segs, int nseg);
 /* Quantise nseg layers (at most 32 per call): per layer a reduction of |w| for the threshold
@@ -388,6 +394,17 @@ int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int t
 /* Gradient of the latent weights (and of the TTQ scales) from d loss / d w~, one pass; mode AQ_TERN_TWN, _TTQ (uses
  * stats[0] = delta as aq_tern_fwd left it) or _INQ (mask). */
 int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, size_t workspace_bytes, void *stream);
+/* aq_tern_bwd with torch.optim.Adam's update (no weight decay / amsgrad) applied in the same pass: per layer
+ * g = rule(dWt) + reg * W (reg = 2 * l2_reg of the regulariser on "weight" tensors, adp_qtz_fan.py:737-743), then W,
+ * adam_m, adam_v are updated in place and adam_step advanced by one; dW (may be NULL) receives g.  TTQ: Wp and Wn
+ * (written through their const pointers) are updated with d loss / d Wp, d loss / d Wn from the same pass and their
+ * own Adam state; dWp / dWn (may be NULL) receive the two gradients.  The optimizer-side analogue of
+ * aq_synth_bwd_adam for the quantisers the reference only cites; any number of layers per call up to 32. */
+int aq_tern_bwd_adam(const aq_tern_seg *segs, int nseg, int mode, double lr, double beta1, double beta2, double eps,
+                     float reg, void *workspace, size_t workspace_bytes, void *stream);
+/* Effective weights of INQ layers: Wt[i] = mask[i] ? W[i] : frozen[i] for every layer in one launch (the weights a
+ * layer computes with between INQ stages; frozen = the decoded power-of-two levels). */
+int aq_inq_effective(const aq_tern_seg *segs, int nseg, void *stream);
 /* One INQ partition step, in place: every weight with mask 1 and |w| >= tau is rounded to its power-of-two level
  * (exponents n2..n1, or 0) and its mask cleared; codes (may be NULL): 255 = still trainable, 0 = zero,
  * 1 + 2 * (k - n2) + (w < 0) for +-2^k.  The caller derives tau from the magnitude quantile of the stage and

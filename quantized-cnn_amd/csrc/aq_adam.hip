@@ -9,6 +9,7 @@
 // to g, so that g holds the gradient of the whole loss as autograd would have left it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdint>
@@ -61,6 +62,49 @@ __global__ __launch_bounds__(256) void adam_items_kernel(const AdamTab t)
     }
 }
 
+// Tensors of more than one workgroup's worth of elements: a workgroup per ADAM_CHUNK elements, the step counters read as
+// the previous step left them and advanced by adam_bump_kernel afterwards (next launch on the stream).
+constexpr int ADAM_CHUNK = 256 * 16;
+struct AdamBigTab {
+    AdamItem it[ADAM_MAX_ITEMS];
+    int blk0[ADAM_MAX_ITEMS + 1];
+    int nitems;
+    double lr, b1, b2;
+    float omb1, b2f, omb2, eps;
+};
+__global__ __launch_bounds__(256) void adam_chunks_kernel(const AdamBigTab t)
+{
+    int ii = 0;
+    for (int i = 1; i < t.nitems; ++i)
+        if ((int)blockIdx.x >= t.blk0[i]) ii = i;
+    const AdamItem it = t.it[ii];
+    const float tnew = it.step[0] + 1.0f;
+    const double bc1 = 1.0 - pow(t.b1, (double)tnew), bc2 = 1.0 - pow(t.b2, (double)tnew);
+    const float step_size = (float)(t.lr / bc1), rbc2 = (float)(1.0 / sqrt(bc2));
+    const int lo = ((int)blockIdx.x - t.blk0[ii]) * ADAM_CHUNK;
+    const int hi = min(lo + ADAM_CHUNK, it.n);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const float p = it.p[i];
+        float g = it.g[i];
+        if (it.reg != 0.0f) {
+            g = __builtin_fmaf(it.reg, p, g);
+            it.g[i] = g;
+        }
+        const float m0 = it.m[i], v0 = it.v[i];
+        const float m = __builtin_fmaf(t.omb1, g - m0, m0);
+        const float v = __builtin_fmaf(t.omb2 * g, g, t.b2f * v0);
+        const float denom = __builtin_fmaf(sqrtf(v), rbc2, t.eps);
+        it.p[i] = p - step_size * (m / denom);
+        it.m[i] = m;
+        it.v[i] = v;
+    }
+}
+__global__ void adam_bump_kernel(const AdamBigTab t)
+{
+    const int i = threadIdx.x;
+    if (i < t.nitems) t.it[i].step[0] = t.it[i].step[0] + 1.0f;
+}
+
 } // namespace aq
 
 extern "C" int aq_adam_step(const aq_adam_item *items, int nitems, double lr, double beta1, double beta2, double eps, void *stream)
@@ -86,6 +130,25 @@ extern "C" int aq_adam_step(const aq_adam_item *items, int nitems, double lr, do
         }
         t.lr = lr; t.b1 = beta1; t.b2 = beta2;
         t.omb1 = (float)(1.0 - beta1); t.b2f = (float)beta2; t.omb2 = (float)(1.0 - beta2); t.eps = (float)eps;
+        long long most = 0;
+        for (int i = 0; i < n; ++i) most = std::max<long long>(most, items[base + i].n);
+        if (most > 4 * ADAM_CHUNK) {  // some tensor would keep one workgroup busy for long: chunks over many workgroups
+            AdamBigTab b = {};
+            long long blocks = 0;
+            for (int i = 0; i < n; ++i) {
+                b.it[i] = t.it[i];
+                b.blk0[i] = (int)blocks;
+                blocks += std::max<long long>(1, (items[base + i].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+            }
+            b.blk0[n] = (int)blocks;
+            b.nitems = n;
+            b.lr = lr; b.b1 = beta1; b.b2 = beta2;
+            b.omb1 = t.omb1; b.b2f = t.b2f; b.omb2 = t.omb2; b.eps = t.eps;
+            hipLaunchKernelGGL(adam_chunks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+            hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, st, b);
+            if (int rc = check_launch("aq_adam_step")) return rc;
+            continue;
+        }
         hipLaunchKernelGGL(adam_items_kernel, dim3(n), dim3(256), 0, st, t);
         if (int rc = check_launch("aq_adam_step")) return rc;
     }

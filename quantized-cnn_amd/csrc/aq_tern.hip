@@ -453,6 +453,171 @@ __global__ __launch_bounds__(256) void inq_partition_kernel(float *__restrict__ 
     }
 }
 
+// Effective weights of INQ layers: the latent parameter where it is still trainable, the frozen level elsewhere
+// (wt = mask ? w : frozen).  The frozen values come decoded (the caller refreshes them once per INQ stage).
+__global__ __launch_bounds__(256) void inq_effective_kernel(const TernTab tab)
+{
+    const int si = tern_segment(tab);
+    const TernSegDev &s = tab.s[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = ((int)blockIdx.x - s.blk0) * 4 + wave;
+    if (wt >= s.nwave) return;
+    const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
+    const float *frozen = s.dwt;  // (the table's second input stream)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e + k < s.n) s.wt[e + k] = s.mask[e + k] ? s.w[e + k] : frozen[e + k];
+    }
+}
+
+// The quantiser's gradient rule with torch.optim.Adam's update of the latent weights applied in registers: the
+// straight-through gradient (MODE as in tern_bwd_kernel) plus reg * w (the l2 regulariser's 2 * l2_reg * w) never
+// travels through memory unless dw is asked for.  Every wavefront reads the step counter as the previous step left
+// it; the second-stage kernel (one workgroup per layer, next launch on the stream) advances it.
+constexpr int TERN_ADAM_MAX_SEGS = 16;  // per launch: the tables travel in the kernel arguments
+struct TernAdamSeg {
+    float *m, *v;
+    const float *step;
+};
+struct TernAdamTab {
+    TernTab t;
+    TernAdamSeg a[TERN_ADAM_MAX_SEGS];
+    double lr, b1, b2;
+    float omb1, b2f, omb2, eps, reg;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tern_bwd_adam_kernel(const TernAdamTab tab)
+{
+    constexpr int U = 4;  // 16-byte loads per lane and stream, four streams: sixteen loads in flight per lane
+    const int si = tern_segment(tab.t);
+    const TernSegDev &s = tab.t.s[si];
+    const TernAdamSeg &a = tab.a[si];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = (int)blockIdx.x - s.blk0;
+    const int wt = blk * 4 + wave;
+    const long long e0 = (long long)wt * (256 * U);
+    float delta = 0.0f, pos = 1.0f, neg = 1.0f;
+    if (MODE == 1) {
+        delta = s.stats[0];
+        pos = s.wp[0];
+        neg = s.wn[0];
+    }
+    const float tnew = a.step[0] + 1.0f;
+    const double bc1 = 1.0 - pow(tab.b1, (double)tnew), bc2 = 1.0 - pow(tab.b2, (double)tnew);
+    const float step_size = (float)(tab.lr / bc1), rbc2 = (float)(1.0 / sqrt(bc2));
+    float g[U][4], w[U][4], m0[U][4], v0[U][4];
+    const bool vec = (((uintptr_t)s.dwt | (uintptr_t)s.w | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)s.dw) & 15) == 0;
+    load_run<U, false>(s.dwt, e0, s.n, lane, g, vec);
+    load_run<U, false>(s.w, e0, s.n, lane, w, vec);
+    load_run<U, false>(a.m, e0, s.n, lane, m0, vec);
+    load_run<U, false>(a.v, e0, s.n, lane, v0, vec);
+    float sp = 0.0f, sn = 0.0f;
+    float *wout = const_cast<float *>(s.w);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long e = e0 + 256 * u + 4 * lane;
+        float o[4], pn[4], mn[4], vn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = g[u][k];
+            const float x = w[u][k];
+            if (MODE == 1) {
+                if (x > delta) {
+                    sp += d;
+                    d *= pos;
+                } else if (x < -delta) {
+                    sn += d;
+                    d *= neg;
+                }
+            } else if (MODE == 2) {
+                d = (e + k < s.n && s.mask[e + k]) ? d : 0.0f;
+            }
+            if (tab.reg != 0.0f) d = __builtin_fmaf(tab.reg, x, d);
+            o[k] = d;
+            const float mm = __builtin_fmaf(tab.omb1, d - m0[u][k], m0[u][k]);
+            const float vv = __builtin_fmaf(tab.omb2 * d, d, tab.b2f * v0[u][k]);
+            const float denom = __builtin_fmaf(sqrtf(vv), rbc2, tab.eps);
+            pn[k] = x - step_size * (mm / denom);
+            mn[k] = mm;
+            vn[k] = vv;
+        }
+        if (vec && e + 3 < s.n) {
+            *reinterpret_cast<tern_f4 *>(wout + e) = tern_f4{pn[0], pn[1], pn[2], pn[3]};
+            *reinterpret_cast<tern_f4 *>(a.m + e) = tern_f4{mn[0], mn[1], mn[2], mn[3]};
+            *reinterpret_cast<tern_f4 *>(a.v + e) = tern_f4{vn[0], vn[1], vn[2], vn[3]};
+            if (s.dw) *reinterpret_cast<tern_f4 *>(s.dw + e) = tern_f4{o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < s.n) {
+                    wout[e + k] = pn[k];
+                    a.m[e + k] = mn[k];
+                    a.v[e + k] = vn[k];
+                    if (s.dw) s.dw[e + k] = o[k];
+                }
+        }
+    }
+    if (MODE == 1) {
+        const float vals[2] = {wave_sum(sp), wave_sum(sn)};
+        wave_partials<2>(vals, s.part, wt, s.nwave);
+    }
+}
+
+// Second stage of the fused form, one workgroup per layer: finishes d loss / d Wp, d loss / d Wn (TTQ), applies Adam to
+// the two scales, and advances the step counters the first stage read.
+struct TernScaleAdam {
+    float *wp, *wn;                 // the learned scales (updated in place)
+    float *pm, *pv, *pstep;         // Adam state of Wp
+    float *nm, *nv, *nstep;         // Adam state of Wn
+    float *wstep;                   // step counter of the latent weight
+};
+struct TernScaleTab {
+    TernTab t;
+    TernScaleAdam a[TERN_ADAM_MAX_SEGS];
+    double lr, b1, b2;
+    float omb1, b2f, omb2, eps;
+    int ttq;
+};
+__device__ __forceinline__ void adam_scalar(float *p, float g, float *m, float *v, float *step, const TernScaleTab &tab)
+{
+    const float tnew = step[0] + 1.0f;
+    const double bc1 = 1.0 - pow(tab.b1, (double)tnew), bc2 = 1.0 - pow(tab.b2, (double)tnew);
+    const float step_size = (float)(tab.lr / bc1), rbc2 = (float)(1.0 / sqrt(bc2));
+    const float mm = __builtin_fmaf(tab.omb1, g - m[0], m[0]);
+    const float vv = __builtin_fmaf(tab.omb2 * g, g, tab.b2f * v[0]);
+    const float denom = __builtin_fmaf(sqrtf(vv), rbc2, tab.eps);
+    p[0] = p[0] - step_size * (mm / denom);
+    m[0] = mm;
+    v[0] = vv;
+    step[0] = tnew;
+}
+__global__ __launch_bounds__(1024) void tern_scale_adam_kernel(const TernScaleTab tab)
+{
+    __shared__ float sh[1024];
+    const TernSegDev &s = tab.t.s[blockIdx.x];
+    const TernScaleAdam &a = tab.a[blockIdx.x];
+    float sp = 0.0f, sn = 0.0f;
+    if (tab.ttq) {
+        int nblk;
+        const float *pp = last_level(s, nblk);
+        sp = block_sum_strided(pp, nblk, 2, sh);
+        sn = block_sum_strided(pp + 1, nblk, 2, sh);
+    }
+    if (threadIdx.x == 0) {
+        if (tab.ttq) {
+            if (s.dwp) s.dwp[0] = sp;
+            if (s.dwn) s.dwn[0] = -sn;
+            adam_scalar(a.wp, sp, a.pm, a.pv, a.pstep, tab);
+            adam_scalar(a.wn, -sn, a.nm, a.nv, a.nstep, tab);
+        }
+        a.wstep[0] = a.wstep[0] + 1.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- host side
 
 static inline int tern_waves(long long n, int epw) { return (int)((n + epw - 1) / epw); }
@@ -620,6 +785,76 @@ int aq_inq_partition(float *W, uint8_t *mask, uint8_t *codes, long long n, float
     hipLaunchKernelGGL(inq_partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), W, mask, codes, n, tau,
                        n1, n2);
     return check_launch("aq_inq_partition");
+}
+
+int aq_inq_effective(const aq_tern_seg *segs, int nseg, void *stream)
+{
+    using namespace aq;
+    if (int rc = tern_validate("aq_inq_effective", segs, nseg)) return rc;
+    for (int i = 0; i < nseg; ++i)
+        AQ_REQUIRE(segs[i].mask && segs[i].frozen && segs[i].Wt, -EFAULT, "aq_inq_effective: layer %d: mask / frozen / Wt is NULL", i);
+    TernTab tab;
+    aq_tern_seg tmp[TERN_MAX_SEGS];
+    for (int i = 0; i < nseg; ++i) {
+        tmp[i] = segs[i];
+        tmp[i].dWt = segs[i].frozen;  // the kernels' second input stream
+    }
+    const int blocks = tern_table(tmp, nseg, nullptr, tab);
+    AQ_REQUIRE(blocks > 0, -E2BIG, "aq_inq_effective: too many elements for one launch");
+    hipLaunchKernelGGL(inq_effective_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
+    return check_launch("aq_inq_effective");
+}
+
+int aq_tern_bwd_adam(const aq_tern_seg *segs, int nseg, int mode, double lr, double beta1, double beta2, double eps, float reg, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    using namespace aq;
+    if (int rc = tern_validate("aq_tern_bwd_adam", segs, nseg)) return rc;
+    AQ_REQUIRE(mode == AQ_TERN_TWN || mode == AQ_TERN_TTQ || mode == AQ_TERN_INQ, -EINVAL, "aq_tern_bwd_adam: mode %d", mode);
+    AQ_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, -EDOM, "aq_tern_bwd_adam: lr=%g betas=(%g, %g) eps=%g out of range",
+               lr, beta1, beta2, eps);
+    for (int i = 0; i < nseg; ++i) {
+        const aq_tern_seg &q = segs[i];
+        AQ_REQUIRE(q.dWt && q.adam_m && q.adam_v && q.adam_step, -EFAULT, "aq_tern_bwd_adam: layer %d: dWt / Adam state is NULL", i);
+        AQ_REQUIRE(mode != AQ_TERN_TTQ || (q.Wp && q.Wn && q.stats && q.Wp_m && q.Wp_v && q.Wp_step && q.Wn_m && q.Wn_v && q.Wn_step), -EFAULT,
+                   "aq_tern_bwd_adam: layer %d: TTQ needs Wp, Wn, stats and the Adam state of both scales", i);
+        AQ_REQUIRE(mode != AQ_TERN_INQ || q.mask, -EFAULT, "aq_tern_bwd_adam: layer %d: INQ needs the partition mask", i);
+        for (int k = 0; k < i; ++k)
+            AQ_REQUIRE(segs[k].adam_step != q.adam_step, -EINVAL, "aq_tern_bwd_adam: layers %d and %d share a step counter", k, i);
+    }
+    const size_t need = tern_ws_bytes(segs, nseg);
+    AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
+               "aq_tern_bwd_adam: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t off = 0;
+    for (int base = 0; base < nseg; base += TERN_ADAM_MAX_SEGS) {
+        const int n = std::min(TERN_ADAM_MAX_SEGS, nseg - base);
+        TernAdamTab tab = {};
+        const int blocks = tern_table(segs + base, n, static_cast<char *>(workspace) + off, tab.t, TERN_ELEMS_PER_WAVE_2IN);
+        AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_bwd_adam: too many elements for one launch");
+        for (int i = 0; i < n; ++i) {
+            off += tern_seg_bytes(segs[base + i].n);
+            tab.a[i] = TernAdamSeg{segs[base + i].adam_m, segs[base + i].adam_v, segs[base + i].adam_step};
+        }
+        tab.lr = lr; tab.b1 = beta1; tab.b2 = beta2;
+        tab.omb1 = (float)(1.0 - beta1); tab.b2f = (float)beta2; tab.omb2 = (float)(1.0 - beta2); tab.eps = (float)eps; tab.reg = reg;
+        if (mode == AQ_TERN_TTQ) hipLaunchKernelGGL(tern_bwd_adam_kernel<1>, dim3(blocks), dim3(256), 0, st, tab);
+        else if (mode == AQ_TERN_INQ) hipLaunchKernelGGL(tern_bwd_adam_kernel<2>, dim3(blocks), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL(tern_bwd_adam_kernel<0>, dim3(blocks), dim3(256), 0, st, tab);
+        if (mode == AQ_TERN_TTQ) launch_levels<2, -1>(tab.t, st);
+        TernScaleTab sc = {};
+        sc.t = tab.t;
+        for (int i = 0; i < n; ++i) {
+            const aq_tern_seg &q = segs[base + i];
+            sc.a[i] = TernScaleAdam{const_cast<float *>(q.Wp), const_cast<float *>(q.Wn), q.Wp_m, q.Wp_v, q.Wp_step, q.Wn_m, q.Wn_v, q.Wn_step, q.adam_step};
+        }
+        sc.lr = lr; sc.b1 = beta1; sc.b2 = beta2;
+        sc.omb1 = tab.omb1; sc.b2f = tab.b2f; sc.omb2 = tab.omb2; sc.eps = tab.eps;
+        sc.ttq = mode == AQ_TERN_TTQ ? 1 : 0;
+        hipLaunchKernelGGL(tern_scale_adam_kernel, dim3(n), dim3(second_stage_threads(tab.t)), 0, st, sc);
+        if (int rc = check_launch("aq_tern_bwd_adam")) return rc;
+    }
+    return 0;
 }
 
 } // extern "C"

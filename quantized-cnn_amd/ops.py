@@ -672,13 +672,13 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, betas=(0.9, 0.999
 _TERN_MODES = {"twn": _lib.TERN_TWN, "ttq": _lib.TERN_TTQ, "inq": _lib.TERN_INQ}
 
 
-def tern_forward(ws, mode="twn", factor=0.7, threshold_from_max=False, Wp=None, Wn=None, codes=True, packed=False, decoded=True):
+def tern_forward(ws, mode="twn", factor=0.7, threshold_from_max=False, Wp=None, Wn=None, codes=True, packed=False, decoded=True, out_Wt=None):
     """Ternary quantisation of a list of weight tensors in one call (five small launches for all of them):
     delta = factor * mean|w| (threshold_from_max: factor * max|w|); code 1 where w > delta, 2 where w < -delta, else 0.
     mode "twn": both scales = mean of |w| above delta; "ttq": scales are the learned Wp[i], Wn[i] (one-element tensors).
     Returns one dict per tensor: "codes" uint8 (shape of w), "packed" uint8 bytes (2 bits per code), "Wt" = q[codes],
     "stats" fp32 [4] = (delta, positive scale, negative scale, number of non-zero codes), "q" fp32 [3] = (0, +pos, -neg).
-    At most 32 tensors per call."""
+    out_Wt: optional list of preallocated fp32 tensors that receive the decoded weights (e.g. views of one flat buffer)."""
     n = len(ws)
     if mode not in ("twn", "ttq"):
         raise ValueError("tern_forward: mode %r (twn or ttq)" % (mode,))
@@ -703,8 +703,13 @@ def tern_forward(ws, mode="twn", factor=0.7, threshold_from_max=False, Wp=None, 
                 d["packed"] = torch.empty((w.numel() + 3) // 4, dtype=torch.uint8, device=dev)
                 segs[i].packed = d["packed"].data_ptr()
             if decoded:
-                d["Wt"] = torch.empty(w.shape, dtype=torch.float32, device=dev)
-                segs[i].Wt = d["Wt"].data_ptr()
+                if out_Wt is not None:
+                    if out_Wt[base + i].numel() != w.numel():
+                        raise ValueError("tern_forward: out_Wt[%d] has %d elements, the weight %d" % (base + i, out_Wt[base + i].numel(), w.numel()))
+                    d["Wt"] = out_Wt[base + i]
+                else:
+                    d["Wt"] = torch.empty(w.shape, dtype=torch.float32, device=dev)
+                segs[i].Wt = _lib.ptr(d["Wt"], name="Wt")
             if mode == "ttq":
                 segs[i].Wp = _lib.ptr(Wp[base + i], name="Wp")
                 segs[i].Wn = _lib.ptr(Wn[base + i], name="Wn")
@@ -747,6 +752,65 @@ def tern_backward(ws, dWts, mode, stats=None, Wp=None, Wn=None, masks=None):
         wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib().aq_tern_bwd(segs, len(chunk), _TERN_MODES[mode], wsb.data_ptr(), nbytes, _lib.stream()))
     return dWs, dps, dns
+
+
+def tern_backward_adam(ws, dWts, mode, exp_avg, exp_avg_sq, steps, lr, betas=(0.9, 0.999), eps=1e-8, reg=0.0, stats=None, Wp=None, Wn=None,
+                       scale_state=None, masks=None, out_dW=None, out_dscale=None):
+    """tern_backward with torch.optim.Adam's update of the latent weights (and of the TTQ scales) applied in the same
+    pass: ws[i], exp_avg[i], exp_avg_sq[i] are updated in place, steps[i] (one-element fp32 tensors, the optimizer's
+    state["step"]) advanced by one; reg * w is added to the gradient first (the regulariser's 2 * l2_reg * w).
+    mode "ttq": Wp[i], Wn[i] are updated too, from scale_state[i] = (Wp exp_avg, Wp exp_avg_sq, Wp step, Wn exp_avg,
+    Wn exp_avg_sq, Wn step).  out_dW: optional tensors that receive the latent gradients (they are not stored otherwise);
+    out_dscale[i] = (dWp, dWn) one-element tensors likewise for the TTQ scale gradients."""
+    n = len(ws)
+    for base in range(0, n, 32):
+        chunk = ws[base:base + 32]
+        segs = (_lib.AqTernSeg * len(chunk))()
+        dev = chunk[0].device
+        for i, w in enumerate(chunk):
+            j = base + i
+            for t, what in ((dWts[j], "gradient"), (exp_avg[j], "exp_avg"), (exp_avg_sq[j], "exp_avg_sq")):
+                if t.numel() != w.numel():
+                    raise ValueError("tern_backward_adam: %s %d has %d elements, the weight %d" % (what, j, t.numel(), w.numel()))
+            segs[i].W, segs[i].n = _lib.ptr(w, name="w"), w.numel()
+            segs[i].dWt = _lib.ptr(dWts[j], name="dWt")
+            segs[i].adam_m, segs[i].adam_v = _lib.ptr(exp_avg[j], name="exp_avg"), _lib.ptr(exp_avg_sq[j], name="exp_avg_sq")
+            segs[i].adam_step = _lib.ptr(steps[j], name="step")
+            if out_dW is not None:
+                segs[i].dW = _lib.ptr(out_dW[j], name="dW")
+            if mode == "ttq":
+                segs[i].stats = _lib.ptr(stats[j], name="stats")
+                segs[i].Wp, segs[i].Wn = _lib.ptr(Wp[j], name="Wp"), _lib.ptr(Wn[j], name="Wn")
+                st = scale_state[j]
+                segs[i].Wp_m, segs[i].Wp_v, segs[i].Wp_step = (_lib.ptr(t, name="Wp state") for t in st[:3])
+                segs[i].Wn_m, segs[i].Wn_v, segs[i].Wn_step = (_lib.ptr(t, name="Wn state") for t in st[3:])
+                if out_dscale is not None:
+                    segs[i].dWp, segs[i].dWn = _lib.ptr(out_dscale[j][0], name="dWp"), _lib.ptr(out_dscale[j][1], name="dWn")
+            if mode == "inq":
+                segs[i].mask = _lib.ptr(masks[j], torch.uint8, "mask")
+        nbytes = _lib.lib().aq_tern_workspace_bytes(segs, len(chunk))
+        wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().aq_tern_bwd_adam(segs, len(chunk), _TERN_MODES[mode], float(lr), float(betas[0]), float(betas[1]), float(eps), float(reg),
+                                               wsb.data_ptr(), nbytes, _lib.stream()))
+
+
+def inq_effective(ws, masks, frozen, out=None):
+    """Effective weights of INQ layers in one launch: out[i] = where(masks[i] != 0, ws[i], frozen[i])."""
+    n = len(ws)
+    outs = out if out is not None else [torch.empty_like(w) for w in ws]
+    for base in range(0, n, 32):
+        chunk = ws[base:base + 32]
+        segs = (_lib.AqTernSeg * len(chunk))()
+        for i, w in enumerate(chunk):
+            j = base + i
+            if masks[j].numel() != w.numel() or frozen[j].numel() != w.numel() or outs[j].numel() != w.numel():
+                raise ValueError("inq_effective: layer %d: mask / frozen / out do not match the weight's %d elements" % (j, w.numel()))
+            segs[i].W, segs[i].n = _lib.ptr(w, name="w"), w.numel()
+            segs[i].mask = _lib.ptr(masks[j], torch.uint8, "mask")
+            segs[i].frozen = _lib.ptr(frozen[j], name="frozen")
+            segs[i].Wt = _lib.ptr(outs[j], name="out")
+        _lib.check(_lib.lib().aq_inq_effective(segs, len(chunk), _lib.stream()))
+    return outs
 
 
 def inq_partition(w, mask, tau, n1, n2, codes=None):

@@ -109,6 +109,11 @@ class ResNet18(nn.Module):
         self._synthesize_all()
         ternary.quantize_all([m for m in self.modules() if isinstance(m, ternary._TernBase)])
         ternary.inq_all([m for m in self.modules() if isinstance(m, ternary.INQConv2d)])
+        return self.forward_body(x)
+
+    def forward_body(self, x):
+        """The graph with every layer's (quantised / effective) weight already handed down: by forward above, or by a
+        fused training step (train.FusedTernaryStep)."""
         c0 = self.conv0
         out = layers.conv3x3(x, c0.weight, 2, None, pad=3)
         out = max_pool_3s2(self.pool0, layers.bn_relu(self.bn0, out))

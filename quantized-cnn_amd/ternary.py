@@ -194,15 +194,29 @@ class TernaryConv2d(_TernBase):
     def forward(self, x, res=None, bn=None, split=False):
         """Same call convention as layers.QConv2d.forward (res added to the output, bn applied to the input, split
         returns the raw input or its pooled shortcut next to the output)."""
-        if isinstance(self._shared, tuple) and torch.is_grad_enabled() and self.ksize == 3 and self.padding == 1:
-            # Training step of a model that quantised all its layers together (quantize_all): the decoded weights are an
-            # autograd tensor, so the layer runs on the same fused nodes as the adaptive layers (layers.QConv2d.forward):
-            # shortcut added in the convolution's epilogue, batch statistics out of the producing convolution,
-            # batch-norm backward coupled to the input-gradient kernel.
-            (q, Wt), self._shared = self._shared, None
-            if bn is not None:
-                return layers.bn_relu_conv(bn, x, Wt, self.stride, None, res, split, stats=self.training)
-            return layers.conv3x3(x, Wt, self.stride, None, res, stats=self.training, split=bool(split))
+        if isinstance(self._shared, tuple) and torch.is_grad_enabled():
+            # Training step of a model that quantised all its layers together (quantize_all, or a fused step that also
+            # hands down the slot of a flat gradient buffer): the decoded weights are an autograd tensor, so the layer runs
+            # on the same fused nodes as the adaptive layers (layers.QConv2d.forward): shortcut added in the convolution's
+            # epilogue, batch statistics out of the producing convolution, batch-norm backward coupled to the
+            # input-gradient kernel, weight gradient deferred into the slot.
+            shared, self._shared = self._shared, None
+            Wt, slot = shared[1], (shared[2] if len(shared) > 2 else None)
+            usual = self.ksize == 3 and self.padding == 1
+            if usual and bn is not None:
+                return layers.bn_relu_conv(bn, x, Wt, self.stride, slot, res, split, stats=self.training)
+            if usual or slot is not None:
+                xs = x
+                if bn is not None:
+                    x, xs = layers.bn_relu(bn, x, split=True) if split else (layers.bn_relu(bn, x), x)
+                    y = layers.conv3x3(x, Wt, self.stride, slot, res, stats=self.training and usual, pad=self.padding)
+                    if isinstance(split, tuple):
+                        return y, layers._Shortcut.apply(xs, *split)
+                    return (y, xs) if split else y
+                if isinstance(split, tuple):
+                    return layers.conv3x3(x, Wt, self.stride, slot, res, stats=self.training and usual, pad=self.padding), layers._Shortcut.apply(x, *split)
+                return layers.conv3x3(x, Wt, self.stride, slot, res, stats=self.training and usual, split=bool(split), pad=self.padding)
+            self._shared = shared  # other kernel sizes without a slot: the generic path below
         xs = x
         if bn is not None:
             if split:
@@ -212,8 +226,8 @@ class TernaryConv2d(_TernBase):
         else:
             z = x
         if isinstance(self._shared, tuple) and torch.is_grad_enabled():  # quantised with the model's other layers (quantize_all)
-            (q, Wt), self._shared = self._shared, None
-            y = _ConvFromQuantized.apply(z, Wt, self, q)
+            shared, self._shared = self._shared, None
+            y = _ConvFromQuantized.apply(z, shared[1], self, shared[0])
         else:
             y = _TernConv.apply(z, self.weight, self.Wp, self.Wn, self, None)
         if res is not None:
@@ -234,8 +248,10 @@ class TernaryLinear(_TernBase):
 
     def forward(self, x):
         if isinstance(self._shared, tuple) and torch.is_grad_enabled():
-            (q, Wt), self._shared = self._shared, None
-            return _LinearFromQuantized.apply(x, Wt, self.bias)
+            shared, self._shared = self._shared, None
+            if len(shared) > 2:  # a fused step: the weight gradient lands in its slot of the flat buffer
+                return layers._LinearIO.apply(x, shared[1], self.bias, shared[2])
+            return _LinearFromQuantized.apply(x, shared[1], self.bias)
         return _TernLinear.apply(x, self.weight, self.bias, self.Wp, self.Wn, self, None)
 
 
@@ -303,12 +319,18 @@ class INQConv2d(nn.Module):
         self.register_buffer("exponents", torch.zeros(2, dtype=torch.int32))  # (n1, n2), fixed at the first stage
         self._have_exp = False
         self._shared = None  # effective weight handed down by the owning model for the current step (inq_all)
+        self._slot = None
         self._cache = None
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         """mask / codes / exponents travel with the state_dict; whether a first stage has fixed the exponents is derived
         from them, so that a reloaded layer computes with its frozen levels and continues its stages."""
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self.buffers_changed()
+
+    def buffers_changed(self):
+        """To be called after mask / codes / exponents were written behind torch's version counters (through .data, by a
+        collective, by a kernel): re-derives whether a stage has run and refreshes the decoded frozen values in place."""
         self._have_exp = bool((self.mask == 0).any()) or bool(self.exponents.any())
         self._refresh_frozen()
 
@@ -367,6 +389,9 @@ class INQConv2d(nn.Module):
         """The weights the layer computes with: trainable entries from the parameter, frozen ones from their codes."""
         if self._shared is not None and torch.is_grad_enabled():  # computed with the model's other layers (inq_all)
             w, self._shared = self._shared, None
+            if isinstance(w, tuple):  # a fused step: (effective weight, its slot in the flat gradient buffer)
+                self._slot = w[1]
+                return w[0]
             return w
         maskb, frozen = self._frozen_values()
         return _InqMask.apply(self.weight, self.mask, maskb, frozen)
@@ -380,9 +405,13 @@ class INQConv2d(nn.Module):
         return torch.tensor(q, dtype=torch.float32, device=self.weight.device)
 
     def forward(self, x, res=None, bn=None, split=False):
-        if bn is not None and self.ksize == 3 and self.padding == 1 and torch.is_grad_enabled():
+        self._slot = None
+        w = self.effective_weight()
+        slot, self._slot = self._slot, None
+        usual = self.ksize == 3 and self.padding == 1
+        if bn is not None and usual and torch.is_grad_enabled():
             # the fused nodes of the adaptive layers (layers.QConv2d.forward)
-            return layers.bn_relu_conv(bn, x, self.effective_weight(), self.stride, None, res, split, stats=self.training)
+            return layers.bn_relu_conv(bn, x, w, self.stride, slot, res, split, stats=self.training)
         xs = x
         if bn is not None:
             if split:
@@ -391,7 +420,7 @@ class INQConv2d(nn.Module):
                 z = layers.bn_relu(bn, x)
         else:
             z = x
-        y = layers.conv3x3(z, self.effective_weight(), self.stride, None, res, pad=self.padding)
+        y = layers.conv3x3(z, w, self.stride, slot, res, stats=self.training and usual and torch.is_grad_enabled(), pad=self.padding)
         if isinstance(split, tuple):
             return y, layers._Shortcut.apply(xs, *split)
         return (y, xs) if split else y
@@ -490,13 +519,22 @@ class ResNet(nn.Module):
     def _quantize_all(self):
         quantize_all(self.quant_layers())
 
+    def inq_layers(self):
+        return [m for m in self.modules() if isinstance(m, INQConv2d)]
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("the quantized ResNet runs on the HIP device only (input is on %s)" % x.device)
         self._quantize_all()
-        inq_all([m for m in self.modules() if isinstance(m, INQConv2d)])
+        inq_all(self.inq_layers())
+        return self.forward_body(x)
+
+    def forward_body(self, x):
+        """The graph with the quantised / effective weights of all layers already handed down (forward, or a fused step)."""
         c0 = self.conv0
-        out = layers.conv3x3(x, c0.weight, 1, None)
+        # inside a step that defers the weight-gradient reductions the stem joins them (layers.QResNet.stem)
+        slot = getattr(self, "_stem_slot", None) if layers._wgrad_deferred is not None else None
+        out = layers.conv3x3(x, c0.weight, 1, slot, stats=self.training)
         out = layers.bn_relu(self.bn0, out)
         out = self.layer3(self.layer2(self.layer1(out)))
         out = layers.bn_relu_pool(self.bnlast, self.ap, out)

@@ -86,6 +86,9 @@ class DataParallel:
                     t.data.copy_(h)
                 else:
                     dist.broadcast(t.data, 0, group=process_group)
+            for m in model.modules():  # state derived from buffers (INQ layers: decoded frozen levels) follows the broadcast
+                if hasattr(m, "buffers_changed"):
+                    m.buffers_changed()
 
     def reduce_flat(self, flat, average=True):
         """In-place mean (average=False: sum, for gradients already scaled by 1/world) over ranks of one flat
@@ -99,6 +102,23 @@ class DataParallel:
             self.dist.all_reduce(flat, group=self.group)
         if average:
             flat.div_(self.world)
+
+    def reduce_buckets(self, buckets):
+        """In-place SUM over ranks of several pieces of a gradient buffer (views of one flat tensor): every piece an
+        asynchronous all-reduce, issued back to back in the given order and awaited together, so that the
+        collectives pipeline on the links instead of running one after the other behind host round trips."""
+        if self.host_staged:
+            hs = [b.cpu() if b.is_cuda else b for b in buckets]
+            works = [self.dist.all_reduce(h, group=self.group, async_op=True) for h in hs]
+            for w in works:
+                w.wait()
+            for b, h in zip(buckets, hs):
+                if h is not b:
+                    b.copy_(h)
+            return
+        works = [self.dist.all_reduce(b, group=self.group, async_op=True) for b in buckets]
+        for w in works:
+            w.wait()  # (makes the current stream wait for the collective; the host does not block)
 
     def reduce_dense(self):
         if self.world == 1:
@@ -534,3 +554,240 @@ class FusedTrainStep:
         torch.cuda.synchronize()
         self._graphs = (ga, gb)
         # capture does not execute: parameters are untouched until the first replay
+
+
+class FusedTernaryStep:
+    """FusedTrainStep's arrangement for the models whose layers are ternary (TWN / TTQ) or incremental power-of-two
+    (INQ) quantised - ternary.ResNet, resnet18.ResNet18 in those modes (the quantisers the reference's README cites;
+    no reference implementation, parity unpinned):
+
+        graph A : ONE quantiser call for every layer (aq_tern_fwd / aq_inq_effective) -> quantised weights in one flat
+                  buffer; forward; CrossEntropy + l2 on the "weight" tensors (adp_qtz_fan.py:737-743); backward with the
+                  quantised weights as leaves -> d loss / d w~ of every layer in one flat buffer, the weight gradients
+                  of layers of one shape as one launch each; the dense gradients gathered behind them for the exchange
+        comm    : all-reduce of that buffer in buckets (only when world_size > 1; never captured), see `bucket_bytes`
+        graph B : the quantiser's gradient rule (straight-through scaling / masks, d loss / d Wp, d loss / d Wn as masked
+                  sums) with Adam of the latent weights and of the scales in the same pass (aq_tern_bwd_adam); Adam of
+                  the remaining parameters in one call (aq_adam_step), regulariser gradient folded in
+
+    Data parallel: d loss / d Wp, d loss / d Wn and the latent gradients are linear in d loss / d w~ with coefficients
+    that depend only on replicated parameters, so reducing d loss / d w~ and applying the rule on every rank equals
+    reducing the rule's outputs; INQ masks the REDUCED gradient on every rank (mask and frozen levels are replicated
+    state), so replicas stay bit-identical: every rank applies the same arithmetic to the same reduced buffer.
+
+    bucket_bytes: the exchange buffer [d w~ of all layers | dense gradients] is all-reduced in consecutive pieces of
+    about this many bytes, issued back to back as asynchronous collectives and awaited together.  Default 8 MiB: over
+    xGMI a ring all-reduce is bound per link (~153 GB/s), pieces of 4-16 MiB reach the link rate while several in flight
+    keep all seven links busy; ResNet-20 (1.1 MB) is a single piece, ResNet-18 (45 MB) six."""
+
+    def __init__(self, model, config, module=None, dp=None, use_graph=True, force_exchange=False, bucket_bytes=8 << 20, keep_grads=False):
+        """keep_grads: also store what autograd would have left in .grad of the latent weights and of the TTQ scales (the
+        fused update does not need them in memory; tests and gradient statistics do)."""
+        from . import ternary
+        self.model, self.config, self.dp = model, config, dp
+        self.module = module if module is not None else ternary
+        if force_exchange and dp is None:
+            raise ValueError("force_exchange needs a DataParallel object (dp=...) to run the exchange with")
+        self.force_exchange, self.use_graph, self.bucket_bytes = bool(force_exchange), bool(use_graph), int(bucket_bytes)
+        if not hasattr(model, "forward_body"):
+            raise TypeError("FusedTernaryStep: the model needs forward_body(x) (ternary.ResNet, resnet18.ResNet18)")
+        self.tern = [m for m in model.modules() if isinstance(m, ternary._TernBase)]
+        self.inq = [m for m in model.modules() if isinstance(m, ternary.INQConv2d)]
+        if bool(self.tern) == bool(self.inq):
+            raise ValueError("FusedTernaryStep: the model must hold ternary layers or INQ layers (found %d / %d)" % (len(self.tern), len(self.inq)))
+        if any(isinstance(m, layers._QuantBase) for m in model.modules()):
+            raise ValueError("FusedTernaryStep: adaptive (p_c / q_level) layers belong to FusedTrainStep")
+        self.qlayers = self.tern or self.inq
+        if self.tern:
+            keys = {(l.mode_q, l.factor, l.threshold_from_max) for l in self.tern}
+            if len(keys) != 1:
+                raise ValueError("FusedTernaryStep: all ternary layers must share mode, factor and threshold rule (found %s)" % sorted(keys))
+            self.mode, self.factor, self.from_max = next(iter(keys))
+        else:
+            self.mode = "inq"
+        dev = next(model.parameters()).device
+        self.ws = [l.weight for l in self.qlayers]
+        self.scales = [(l.Wp, l.Wn) for l in self.qlayers] if self.mode == "ttq" else []
+        own = {id(p) for p in self.ws} | {id(p) for pair in self.scales for p in pair}
+        named = list(model.named_parameters())
+        self.dense = [p for n, p in named if id(p) not in own and p.requires_grad]
+        self.reg_all = [p for n, p in named if "weight" in n]                       # the regulariser's tensors (value)
+        self.dense_reg = {id(p) for n, p in named if "weight" in n and id(p) not in own}
+        self.opts = make_optimizers(model, config, capturable=use_graph, fused=True)
+        if self.opts.roles != ("rest",):
+            raise ValueError("FusedTernaryStep: expected one optimizer over all parameters, found roles %s" % (self.opts.roles,))
+        g0 = self.opts[0].param_groups[0]
+        if g0["amsgrad"] or g0["maximize"] or g0["weight_decay"]:
+            raise ValueError("FusedTernaryStep: plain Adam only (no amsgrad / maximize / weight_decay)")
+        nW = sum(w.numel() for w in self.ws)
+        nD = sum(p.numel() for p in self.dense)
+        self.nW = nW
+        self.W_flat = torch.empty(nW, dtype=torch.float32, device=dev)
+        self.g_flat = torch.zeros(nW + nD, dtype=torch.float32, device=dev)  # [d loss / d w~ of all layers | dense grads]
+        self.Wts, self.slots, off = [], [], 0
+        for w in self.ws:
+            n = w.numel()
+            self.Wts.append(self.W_flat[off:off + n].view(w.shape))
+            self.slots.append(self.g_flat[off:off + n].view(w.shape))
+            off += n
+        c0 = getattr(model, "conv0", None)
+        self.stem_slot = self.stem_w = None
+        if isinstance(c0, nn.Conv2d) and c0.bias is None and c0.weight.requires_grad and c0.kernel_size == (3, 3) and c0.padding == (1, 1) \
+                and c0.stride in ((1, 1), (2, 2)):
+            self.stem_w, self.stem_slot = c0.weight, torch.zeros_like(c0.weight)
+        self.keep_grads = bool(keep_grads)
+        self.dW_out = [torch.zeros_like(w) for w in self.ws] if keep_grads else None
+        self.dscale_out = [(torch.zeros_like(p), torch.zeros_like(n)) for p, n in self.scales] if keep_grads else None
+        self._graphs = self._key = None
+        self.loss = self.reg = self.logits = None
+
+    @property
+    def _exchange(self):
+        return self.dp is not None and (self.dp.world > 1 or self.force_exchange)
+
+    def _ensure_adam_state(self):
+        o = self.opts[0]
+        for group in o.param_groups:
+            for p in group["params"]:
+                if p.requires_grad and len(o.state[p]) == 0:
+                    o.state[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    o.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    o.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    # ---- the two phases ---------------------------------------------------------------------
+    def _phase_a(self, x, y):
+        from . import ops
+        for p in self.dense:
+            p.grad = None
+        self.model._stem_slot = self.stem_slot
+        ws = [w.detach() for w in self.ws]
+        if self.mode == "inq":
+            fz = [l._frozen_values() for l in self.qlayers]  # persistent tensors, rewritten in place by every INQ stage
+            ops.inq_effective(ws, [l.mask for l in self.qlayers], [f[1] for f in fz], out=self.Wts)
+            for l, W, slot in zip(self.qlayers, self.Wts, self.slots):
+                l._shared = (W.detach().requires_grad_(True), slot)
+        else:
+            kw = dict(Wp=[p.detach() for p, _ in self.scales], Wn=[n.detach() for _, n in self.scales]) if self.mode == "ttq" else {}
+            self.q = ops.tern_forward(ws, self.mode, self.factor, self.from_max, out_Wt=self.Wts, **kw)
+            for l, q, W, slot in zip(self.qlayers, self.q, self.Wts, self.slots):
+                l._shared = (q, W.detach().requires_grad_(True), slot)
+        jobs = []
+        prev = layers.defer_wgrad_reductions(jobs, None)
+        try:
+            logits = self.model.forward_body(x)
+            ss = ops.sumsq([p.detach() for p in self.reg_all]) if self.reg_all else None
+            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(getattr(self.config, "l2_reg", 0.0)), None, ss,
+                                        grad_scale=1.0 / self.dp.world if self._exchange else 1.0)
+            logits.backward(dlogits)
+        finally:
+            layers.defer_wgrad_reductions(*prev)
+        layers.run_deferred_wgrads(jobs)
+        ops.conv_wgrad_reduce(jobs)
+        del jobs
+        if self.stem_slot is not None:
+            self.stem_w.grad = self.stem_slot
+        for l in self.qlayers:
+            l._shared = None
+        if self._exchange:
+            torch.cat([p.grad.reshape(-1) for p in self.dense], out=self.g_flat[self.nW:])
+        self.reg, self.loss = vals[1], vals[2]
+        self.logits = logits.detach()
+
+    def _phase_b(self):
+        from . import ops
+        o = self.opts[0]
+        grp = o.param_groups[0]
+        coef = 2.0 * float(getattr(self.config, "l2_reg", 0.0))
+        if self._exchange:
+            off = self.nW
+            for p in self.dense:  # the update reads (and completes) the reduced gradients where they lie
+                p.grad = self.g_flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        st = [o.state[w] for w in self.ws]
+        kw = {}
+        if self.mode == "ttq":
+            sst = [(o.state[p], o.state[n]) for p, n in self.scales]
+            kw = dict(stats=[q["stats"] for q in self.q], Wp=[p.detach() for p, _ in self.scales], Wn=[n.detach() for _, n in self.scales],
+                      scale_state=[(a["exp_avg"], a["exp_avg_sq"], a["step"], b["exp_avg"], b["exp_avg_sq"], b["step"]) for a, b in sst])
+        elif self.mode == "inq":
+            kw = dict(masks=[l.mask for l in self.qlayers])
+        ops.tern_backward_adam([w.detach() for w in self.ws], self.slots, self.mode, [t["exp_avg"] for t in st], [t["exp_avg_sq"] for t in st],
+                               [t["step"] for t in st], lr=grp["lr"], betas=grp["betas"], eps=grp["eps"], reg=coef, out_dW=self.dW_out,
+                               out_dscale=self.dscale_out if self.mode == "ttq" else None, **kw)
+        if self.keep_grads:
+            for w, g in zip(self.ws, self.dW_out):
+                w.grad = g
+            for (p, n), (gp, gn) in zip(self.scales, self.dscale_out or []):
+                p.grad, n.grad = gp, gn
+        prm = [p for p in self.dense if p.grad is not None]
+        dst = [o.state[p] for p in prm]
+        ops.adam_step([p.detach() for p in prm], [p.grad for p in prm], [t["exp_avg"] for t in dst], [t["exp_avg_sq"] for t in dst],
+                      [t["step"] for t in dst], lr=grp["lr"], betas=grp["betas"], eps=grp["eps"],
+                      regs=[coef if id(p) in self.dense_reg else 0.0 for p in prm])
+
+    def _comm(self):
+        """The exchange: the flat buffer in consecutive buckets, asynchronous all-reduces issued back to back."""
+        if not self._exchange:
+            return
+        n = self.g_flat.numel()
+        per = max(1, self.bucket_bytes // 4)
+        nb = max(1, (n + per - 1) // per)
+        per = (n + nb - 1) // nb
+        self.dp.reduce_buckets([self.g_flat[i:min(i + per, n)] for i in range(0, n, per)])
+
+    # ---- driver ------------------------------------------------------------------------------
+    def __call__(self, x, y):
+        if not self.use_graph:
+            self._ensure_adam_state()
+            self._phase_a(x, y)
+            self._comm()
+            self._phase_b()
+            return self.loss
+        key = (tuple(x.shape), tuple(g["lr"] for g in self.opts[0].param_groups), self._exchange)
+        if self._graphs is None or key != self._key:
+            self._capture(x, y)
+            self._key = key
+        if x is not self._sx:
+            self._sx.copy_(x)
+        if y is not self._sy:
+            self._sy.copy_(y)
+        self._graphs[0].replay()
+        if self._graphs[1] is not None:
+            self._comm()
+            self._graphs[1].replay()
+        return self.loss
+
+    def invalidate(self):
+        self._graphs = self._key = None
+
+    def static_inputs(self):
+        return (self._sx, self._sy) if (self.use_graph and self._graphs is not None) else None
+
+    def _capture(self, x, y):
+        _refuse_sync_bn_under_capture(self.model, self.dp)
+        self._sx, self._sy = x.clone(), y.clone()
+        self._ensure_adam_state()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            bufs = [b for b in self.model.buffers()]
+            saved = [b.clone() for b in bufs]
+            self._phase_a(self._sx, self._sy)  # lazy initialisation of whatever stock operators the model still uses
+            for b, v in zip(bufs, saved):
+                b.copy_(v)
+            torch.cuda.synchronize()
+            if self._exchange:
+                with torch.cuda.graph(ga, stream=s):
+                    self._phase_a(self._sx, self._sy)
+                with torch.cuda.graph(gb, stream=s, pool=ga.pool()):
+                    self._phase_b()
+            else:
+                gb = None
+                with torch.cuda.graph(ga, stream=s):
+                    self._phase_a(self._sx, self._sy)
+                    self._phase_b()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graphs = (ga, gb)

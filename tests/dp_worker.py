@@ -7,6 +7,9 @@ mode "gpu_eval" / "gpu_syncbn": one step with separate (unfused) gradients kept,
             resp. as SyncBatchNorm: in both the two half batches must reproduce a full-batch single-process step.
 mode "nccl1": a single rank on the RCCL backend; the two-graphs-around-an-all-reduce form of the step (forced at
             world size 1) against the one-graph form, bit for bit.
+mode "tern_eval": one FusedTernaryStep (--net resnet20 | resnet18 at 64 x 64, --mode_q ttq | twn | inq) with BatchNorm on its
+            running statistics, the exchange in several buckets; "tern_nccl1": the same step on RCCL with one rank, forced
+            exchange against the one-graph form.
 Writes its results to <out>.rank<r>.pt
 """
 import argparse
@@ -36,9 +39,11 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--net", default="resnet20")
+    ap.add_argument("--mode_q", default="ttq")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    if a.mode == "nccl1":
+    if a.mode in ("nccl1", "tern_nccl1"):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
@@ -84,6 +89,53 @@ def main():
         res["losses"], res["losses_forced"] = runs[0][0], runs[1][0]
         res["equal"] = all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
         res["backend"] = dist.get_backend()
+    elif a.mode in ("tern_eval", "tern_nccl1"):
+        import quantized_cnn_amd.ternary as T
+        from quantized_cnn_amd.resnet18 import ResNet18
+        from quantized_cnn_amd.train import FusedTernaryStep
+        c = argparse.Namespace(mode="train", mode_q=a.mode_q, l2_reg=5e-4, lr=1e-3, prim_init="uniform", num_level_conv=32, num_level_fc=32)
+
+        def build(seed):
+            torch.manual_seed(seed)
+            model = (T.ResNet(c, 1) if a.net == "resnet20" else ResNet18(c, num_classes=10)).cuda().train()
+            if a.mode_q == "inq":
+                for m in model.modules():
+                    if isinstance(m, T.INQConv2d):
+                        m.quantize_portion(0.5)
+            return model
+        size = 32 if a.net == "resnet20" else 64
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(8, 3, size, size, generator=g)
+        Y = torch.randint(0, 10, (8,), generator=g)
+        if a.mode == "tern_eval":
+            model = build(7 + rank)  # rank-dependent init on purpose: the broadcast must fix it
+            for m in model.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+            dp = DataParallel(model)
+            per = 8 // world
+            x, y = X[rank * per:(rank + 1) * per].cuda(), Y[rank * per:(rank + 1) * per].cuda()
+            step = FusedTernaryStep(model, c, dp=dp, use_graph=bool(a.graph), keep_grads=True, bucket_bytes=1 << 16)
+            res["loss"] = float(step(x, y))
+            res["reg"] = float(step.reg)
+            res["nbuckets"] = -(-step.g_flat.numel() * 4 // (1 << 16))
+            res["grads"] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+            res["state"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        else:
+            runs = []
+            for force in (False, True):
+                model = build(3)
+                dp = DataParallel(model)
+                step = FusedTernaryStep(model, c, dp=dp, use_graph=bool(a.graph), force_exchange=force, bucket_bytes=1 << 16)
+                assert step._exchange == force
+                losses = [float(step(X.cuda(), Y.cuda())) for _ in range(a.steps)]
+                if a.graph:
+                    assert (step._graphs[1] is not None) == force
+                runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+                dp.close()
+            res["losses"], res["losses_forced"] = runs[0][0], runs[1][0]
+            res["equal"] = all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
+            res["backend"] = dist.get_backend()
     elif a.mode in ("gpu_eval", "gpu_syncbn"):
         import quantized_cnn_amd.adp_qtz_hint as hint
         c = argparse.Namespace(mode="train", prim_init="uniform", num_level_conv=32, num_level_fc=32, l2_reg=5e-4, liar=True,

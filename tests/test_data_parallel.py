@@ -154,3 +154,58 @@ def test_exchange_path_on_rccl_single_rank(tmp_path, graph):
     assert r["backend"] == "nccl"
     assert r["losses"] == r["losses_forced"], (r["losses"], r["losses_forced"])
     assert r["equal"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net,mode_q,graph", [("resnet18", "inq", 0), ("resnet18", "inq", 1), ("resnet20", "ttq", 1), ("resnet20", "twn", 0)])
+def test_two_rank_fused_ternary_step_equals_a_full_batch_autograd_step(tmp_path, net, mode_q, graph):
+    """train.FusedTernaryStep over two ranks (half batches, the flat buffer exchanged in several buckets) against ONE
+    autograd pass over the whole batch through the plain module path, BatchNorm on its running statistics so that the
+    loss is a plain mean over images: every gradient - latent weights after the quantiser's rule, TTQ scales, dense
+    tensors, regulariser included - must agree, and the replicas must hold the same bits after the update.
+    (ResNet-18 at 64 x 64 with INQ layers half frozen; ResNet-20 with TTQ / TWN layers.  Parity unpinned: no reference
+    implementation of these quantisers exists, the check is internal consistency of the data-parallel arrangement.)"""
+    import argparse
+    import quantized_cnn_amd.ternary as T
+    from quantized_cnn_amd.resnet18 import ResNet18
+    r0, r1 = _run("tern_eval", str(tmp_path / "te"), extra=("--net", net, "--mode_q", mode_q, "--graph", str(graph)))
+    assert r0["nbuckets"] >= 2
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    for n in r0["grads"]:
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    c = argparse.Namespace(mode="train", mode_q=mode_q, l2_reg=5e-4, lr=1e-3, prim_init="uniform", num_level_conv=32, num_level_fc=32)
+    torch.manual_seed(7)  # rank 0's initial parameters
+    model = (T.ResNet(c, 1) if net == "resnet20" else ResNet18(c, num_classes=10)).cuda().train()
+    if mode_q == "inq":
+        for m in model.modules():
+            if isinstance(m, T.INQConv2d):
+                m.quantize_portion(0.5)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    size = 32 if net == "resnet20" else 64
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(8, 3, size, size, generator=g).cuda()
+    Y = torch.randint(0, 10, (8,), generator=g).cuda()
+    ce = torch.nn.functional.cross_entropy(model(X), Y)
+    reg = T.model_loss(c, 1, model)
+    (ce + reg).backward()
+    assert abs(r0["reg"] - float(reg)) <= 1e-6 * float(reg)
+    assert abs(0.5 * ((r0["loss"] - r0["reg"]) + (r1["loss"] - r1["reg"])) - float(ce)) <= 1e-5 * float(ce)
+    want = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(want) == set(r0["grads"])
+    for n, w in want.items():
+        err = (r0["grads"][n].double() - w.double()).abs().max().item()
+        assert err <= 5e-5 * w.abs().max().item() + 1e-9, (n, err, w.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [0, 1])
+def test_fused_ternary_exchange_path_on_rccl_single_rank(tmp_path, graph):
+    """Backend "nccl" (RCCL), one rank: FusedTernaryStep in its multi-GPU form (graph A, bucketed in-place all-reduces
+    on the device, graph B) gives the bits of the one-graph form."""
+    (r,) = _run("tern_nccl1", str(tmp_path / "tn"), world=1, extra=("--steps", "4", "--graph", str(graph), "--mode_q", "ttq"))
+    assert r["backend"] == "nccl"
+    assert r["losses"] == r["losses_forced"], (r["losses"], r["losses_forced"])
+    assert r["equal"]
