@@ -772,7 +772,9 @@ class FusedTernaryStep:
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
-            bufs = [b for b in self.model.buffers()]
+            # (only the BatchNorm running statistics: the pass writes nothing else, and INQ layers key their decoded
+            # frozen levels on the version counters of their own buffers)
+            bufs = [b for m in self.model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) for b in m.buffers(recurse=False)]
             saved = [b.clone() for b in bufs]
             self._phase_a(self._sx, self._sy)  # lazy initialisation of whatever stock operators the model still uses
             for b, v in zip(bufs, saved):

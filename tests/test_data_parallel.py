@@ -16,14 +16,23 @@ from conftest import ROOT
 
 
 def _run(mode, out, world=2, extra=()):
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:  # a port nobody holds right now (a fixed one may still be held by the previous test's ranks)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "--mode", mode, "--out", out, *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=150)[0].decode() for p in procs]
+    try:
+        logs = [p.communicate(timeout=150)[0].decode() for p in procs]
+    finally:
+        for p in procs:  # a rank that outlives the test (a peer died, a collective waits) must not keep the port or the GPU
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
     return [torch.load("%s.rank%d.pt" % (out, r), weights_only=False) for r in range(world)]

@@ -64,7 +64,9 @@ def test_first_step_gradients_equal_the_autograd_path(mode_q, net):
     for n, p in m2.named_parameters():
         assert p.grad is not None, n
         err = float((p.grad - want[n]).abs().max())
-        assert err <= 2e-5 * float(want[n].abs().max()) + 1e-9, (n, err, float(want[n].abs().max()))
+        # (the two scale gradients are sums of d loss / d w~ over up to 2.4 M weights that cancel to a fraction of their terms)
+        tol = 2e-4 if n.endswith((".Wp", ".Wn")) else 2e-5
+        assert err <= tol * float(want[n].abs().max()) + 1e-9, (n, err, float(want[n].abs().max()))
         seen += 1
     assert seen == len(want)
 
