@@ -337,13 +337,18 @@ int aq_adam_step(const aq_adam_item *items, int nitems, double lr, double beta1,
 /* Tail of the step, `loss = criterion(logits, y) + model_loss(config, beta, model)` (adp_qtz_fan.py:288-289,
  * criterion = nn.CrossEntropyLoss(), :202; model_loss :737-754):
  * aq_sumsq: out[i] = sum of squares of tensor i (HOST arrays of n device pointers / sizes), one launch
- *   per 32 tensors: the `torch.sum(param**2)` terms of the dense "weight" tensors.
+ *   per 32 tensors: the `torch.sum(param**2)` terms of the dense "weight" tensors.  Tensors of more than 16384
+ *   elements are shared by several workgroups, whose partial sums (double) pass through `workspace`
+ *   (aq_sumsq_workspace_bytes(sizes, n) bytes, 8-byte aligned; 0 = none needed, workspace may be NULL) and are
+ *   finished by a second launch; everything beyond a thread's first 64 elements is summed in double.
  * aq_ce_loss: logits [N, C] fp32, labels [N] int64 ->
  *   out[0] = mean cross entropy, out[1] = l2_reg * (sum sumsq_a[0..na) + sum sumsq_b[0..nb)), out[2] = their sum;
  *   dlogits [N, C] (may be NULL) = grad_scale * d out[0] / d logits = grad_scale * (softmax - onehot) / N
  *   (grad_scale = 1 / world size lets a data-parallel job SUM its gradients into the mean without a scaling
  *   pass).  A label outside [0, C) makes out[0] NaN. */
-int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *stream);
+size_t aq_sumsq_workspace_bytes(const long long *sizes, int n);
+int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *workspace, size_t workspace_bytes,
+             void *stream);
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na,
                const float *sumsq_b, int nb, float l2_reg, float grad_scale, float *dlogits, float *out,
                void *stream);

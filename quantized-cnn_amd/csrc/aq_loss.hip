@@ -4,15 +4,21 @@
 // aq_ce_loss: one workgroup computes the cross entropy, its gradient w.r.t. the logits (what autograd
 //             would hand back for d loss = 1) and assembles {ce, reg, loss} from the sums of squares, so
 //             the dozen tiny stock launches of this tail become two.  Fixed summation order, no atomics.
+#include <algorithm>
+
 #include "aq_common.h"
 #include "../../include/aq_hip.h"
 
 namespace aq {
 
 constexpr int SUMSQ_MAX = 32;
+constexpr int SUMSQ_CHUNK = 256 * 64;  // elements per workgroup: a tensor beyond that is shared by several workgroups
 struct SumsqTab {
     const float *p[SUMSQ_MAX];
     long long n[SUMSQ_MAX];
+    int blk0[SUMSQ_MAX + 1];   // first workgroup of every tensor
+    double *part[SUMSQ_MAX];   // per-chunk partial sums of the tensors with more than one chunk
+    int ntensors;
     float *out;
 };
 
@@ -26,15 +32,46 @@ __device__ inline float block_tree_sum(float v, float *sh)  // 256 threads, fixe
     }
     return sh[0];
 }
+__device__ inline double block_tree_sum(double v, double *sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sh[0];
+}
 
+// Per thread an fp32 fma chain over at most 64 elements, everything beyond that in double: the sum of squares of a
+// 2.4 M-element tensor is then as exact as its fp32 result can say (the reference's torch.sum is a pairwise fp32 sum).
 __global__ __launch_bounds__(256) void sumsq_kernel(const SumsqTab t)
 {
-    __shared__ float sh[256];
-    const int i = blockIdx.x;
+    __shared__ double sh[256];
+    int i = 0;
+    for (int k = 1; k < t.ntensors; ++k)
+        if ((int)blockIdx.x >= t.blk0[k]) i = k;
+    const int c = (int)blockIdx.x - t.blk0[i];
+    const long long lo = (long long)c * SUMSQ_CHUNK, hi = min(lo + SUMSQ_CHUNK, t.n[i]);
+    const float *p = t.p[i];
     float a = 0.0f;
-    for (long long k = threadIdx.x; k < t.n[i]; k += 256) a = __builtin_fmaf(t.p[i][k], t.p[i][k], a);
-    const float s = block_tree_sum(a, sh);
-    if (threadIdx.x == 0) t.out[i] = s;
+    for (long long k = lo + threadIdx.x; k < hi; k += 256) a = __builtin_fmaf(p[k], p[k], a);
+    const double s = block_tree_sum((double)a, sh);
+    if (threadIdx.x == 0) {
+        if (t.blk0[i + 1] - t.blk0[i] == 1) t.out[i] = (float)s;
+        else t.part[i][c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const SumsqTab t)
+{
+    __shared__ double sh[256];
+    const int i = blockIdx.x;
+    const int nchunk = t.blk0[i + 1] - t.blk0[i];
+    if (nchunk <= 1) return;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nchunk; k += 256) a += t.part[i][k];
+    const double s = block_tree_sum(a, sh);
+    if (threadIdx.x == 0) t.out[i] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, const long long *__restrict__ labels, int N, int C,
@@ -73,20 +110,49 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
 
 extern "C" {
 
-int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *stream)
+size_t aq_sumsq_workspace_bytes(const long long *sizes, int n)
+{
+    size_t bytes = 0;
+    for (int i = 0; sizes && i < n; ++i) {
+        const long long chunks = (sizes[i] + aq::SUMSQ_CHUNK - 1) / aq::SUMSQ_CHUNK;
+        if (chunks > 1) bytes += (size_t)chunks * sizeof(double);
+    }
+    return bytes;
+}
+
+int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace aq;
     AQ_REQUIRE(n >= 0 && (n == 0 || (tensors && sizes && out)), -EINVAL, "aq_sumsq: bad arguments");
+    const size_t need = aq_sumsq_workspace_bytes(sizes, n);
+    AQ_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && ((uintptr_t)workspace & 7) == 0), -ENOSPC,
+               "aq_sumsq: workspace of %zu bytes (8-byte aligned) needed for the tensors of more than %d elements, %zu given", need, SUMSQ_CHUNK,
+               workspace_bytes);
+    double *ws = static_cast<double *>(workspace);
     for (int base = 0; base < n; base += SUMSQ_MAX) {
         SumsqTab t = {};
         const int m = n - base < SUMSQ_MAX ? n - base : SUMSQ_MAX;
+        long long blocks = 0;
+        bool finish = false;
         for (int i = 0; i < m; ++i) {
             AQ_REQUIRE(sizes[base + i] >= 0 && (sizes[base + i] == 0 || tensors[base + i]), -EINVAL, "aq_sumsq: tensor %d is NULL", base + i);
             t.p[i] = tensors[base + i];
             t.n[i] = sizes[base + i];
+            t.blk0[i] = (int)blocks;
+            const long long chunks = std::max<long long>(1, (sizes[base + i] + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
+            if (chunks > 1) {
+                t.part[i] = ws;
+                ws += chunks;
+                finish = true;
+            }
+            blocks += chunks;
+            AQ_REQUIRE(blocks < (1LL << 31), -E2BIG, "aq_sumsq: too many elements for one launch");
         }
+        t.blk0[m] = (int)blocks;
+        t.ntensors = m;
         t.out = out + base;
-        hipLaunchKernelGGL(sumsq_kernel, dim3(m), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+        hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+        if (finish) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(m), dim3(256), 0, static_cast<hipStream_t>(stream), t);
         if (int rc = check_launch("aq_sumsq")) return rc;
     }
     return 0;

@@ -575,7 +575,7 @@ struct RedTab {
 
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const RedTab tab)
 {
-    __shared__ float sh[1024];
+    __shared__ double sh[1024];  // summed in double: the partials of a layer's dq cancel to a small fraction of their size
     int si = 0;
     for (int i = 1; i < tab.nseg; ++i)
         if ((int)blockIdx.x >= tab.s[i].blk0) si = i;
@@ -586,8 +586,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const RedTab tab)
     const long long chunk = (long long)((int)blockIdx.x - sg.blk0);
     const long long r0 = chunk * 32 * nl;
     const long long r1 = r0 + 32 * nl < sg.n ? r0 + 32 * nl : sg.n;
-    float a = 0.0f;
-    for (long long i = r0 + ln; i < r1; i += nl) a += sg.part[i * width + lvl];
+    double a = 0.0;
+    for (long long i = r0 + ln; i < r1; i += nl) a += (double)sg.part[i * width + lvl];
     sh[tid] = a;
     __syncthreads();
     for (int s = nl >> 1; s >= 1; s >>= 1) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const RedTab tab)
     }
     // a single-chunk level writes the layer's result (outw columns); otherwise one row per chunk
     const bool last = sg.n <= 32 * nl;
-    if (ln == 0 && lvl < (last ? sg.outw : width)) sg.out[(last ? 0 : chunk * width) + lvl] = sh[lvl];
+    if (ln == 0 && lvl < (last ? sg.outw : width)) sg.out[(last ? 0 : chunk * width) + lvl] = (float)sh[lvl];
 }
 
 // ------------------------------------------------------------------------------------ host side

@@ -621,7 +621,9 @@ def sumsq(tensors):
     out = torch.empty(n, dtype=torch.float32, device=tensors[0].device)
     ptrs = (C.c_void_p * n)(*[_lib.ptr(t, name="tensor[%d]" % i) for i, t in enumerate(tensors)])
     sizes = (C.c_longlong * n)(*[t.numel() for t in tensors])
-    _lib.check(_lib.lib().aq_sumsq(ptrs, sizes, n, _lib.ptr(out), _lib.stream()))
+    nbytes = _lib.lib().aq_sumsq_workspace_bytes(sizes, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device) if nbytes else None
+    _lib.check(_lib.lib().aq_sumsq(ptrs, sizes, n, _lib.ptr(out), ws.data_ptr() if ws is not None else None, nbytes, _lib.stream()))
     return out
 
 
