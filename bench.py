@@ -56,6 +56,7 @@ def event_time(fn, iters, warm=3):
 
 def kernel_rooflines(quick):
     import quantized_cnn_amd.ops as ops
+    from quantized_cnn_amd._lib import last_kernel  # the instantiation the most recent call launched (aq_last_kernel)
     dev = "cuda"
     L = 32
     rows = (250_000_000 if not quick else 25_000_000) // L
@@ -67,11 +68,14 @@ def kernel_rooflines(quick):
     W = [torch.empty(rows, device=dev)]
     dp = [torch.empty_like(p)]
     t1 = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, out_W=W), 20, warm=10)
+    k1 = last_kernel()
     t2 = event_time(lambda: ops.synth_backward([p], [q], 4.0, [dW], 1e-3, out_dp=dp), 20, warm=10)
+    k2 = last_kernel()
     # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc on the same
-    # 250 M-element tensor, see profiles/r02_roofline_traffic.json); only valid for the full-size tensor
+    # 250 M-element tensor, see profiles/r03_roofline_traffic.json); only valid for the full-size tensor
     traffic = traffic2 = traffic3 = traffic_codes = traffic_tern = None
-    tf = os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")
+    tj = {}
+    tf = os.path.join(ROOT, "profiles", "r03_roofline_traffic.json")
     if os.path.exists(tf) and not quick:
         try:
             tj = json.load(open(tf))
@@ -81,27 +85,28 @@ def kernel_rooflines(quick):
                 traffic_codes, traffic_tern = tj.get("synth_fwd_codes_only_bytes_per_launch"), tj.get("tern_quantise_bytes_per_call")
         except Exception:
             traffic = traffic2 = traffic3 = traffic_codes = traffic_tern = None
+            tj = {}
     a1 = rows * (4 * L + 4) / t1 / 1e9
     # traffic: not measured in this run; the committed PMC result for the same launch (FETCH_SIZE x 2 + WRITE_SIZE)
-    src = "profiles/r02_roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
-    roof = {"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, false, false, false, 4> (fast arithmetic, streaming loads, 32 rows per wavefront)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
+    src = "profiles/r03_roofline_traffic.json (rocprofv3 --pmc passes of this launch, not collected in this run)" if traffic is not None else None
+    roof = {"bound": "hbm", "kernel": k1 + " (soft weights, fast arithmetic)", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "bytes_per_row": 4 * L + 4, "rows_per_launch": rows, "avg_launch_ms": round(t1 * 1e3, 4)}
     a2 = rows * (8 * L + 4) / t2 / 1e9
-    more = [{"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false, false>", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    more = [{"bound": "hbm", "kernel": k2 + " (gradient of the synthesis, dp_c and dq)", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": traffic2, "bytes_per_row": 8 * L + 4, "rows_per_launch": rows,
              "avg_launch_ms": round(t2 * 1e3, 4)}]
     # the code-emitting forward (hard mode, what an evaluation pass runs: 1-byte code and q[code] per row)
     th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=False, codes=True), 20, warm=10)
     ah = rows * (4 * L + 5) / th / 1e9
-    more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, true> (codes + q[code]; arg-max of p, exact sequence on near ties)",
+    more.append({"bound": "hbm", "kernel": last_kernel() + " (codes + q[code]; arg-max of p, exact sequence on near ties)",
                  "achieved": round(ah, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "traffic": traffic_codes,
                  "bytes_per_row": 4 * L + 5, "rows_per_launch": rows, "avg_launch_ms": round(th * 1e3, 4)})
     # soft W, codes and q[code] together in exact arithmetic (bit-reproducible against the CPU restatement)
     th = event_time(lambda: ops.synth_forward([p], [q], 4.0, soft=True, codes=True), 20, warm=10)
     ah = rows * (4 * L + 9) / th / 1e9
-    more.append({"bound": "hbm", "kernel": "aq::synth_fwd_kernel<8, 2, true, true, false> (W + codes + q[code], exact arithmetic)", "achieved": round(ah, 1),
-                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "bytes_per_row": 4 * L + 9, "rows_per_launch": rows,
+    more.append({"bound": "hbm", "kernel": last_kernel() + " (W + codes + q[code], exact arithmetic)", "achieved": round(ah, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ah / HBM_PEAK_GBS, 4), "traffic": tj.get("synth_fwd_exact_W_codes_bytes_per_launch"), "bytes_per_row": 4 * L + 9, "rows_per_launch": rows,
                  "avg_launch_ms": round(th * 1e3, 4)})
     # 31 levels (adp_qtz_fix): 124-byte rows, no 16-byte alignment
     L31 = 31
@@ -110,18 +115,25 @@ def kernel_rooflines(quick):
     dp31 = [dp[0].view(-1)[:rows * L31].view(rows, L31)]
     # (twenty warm-up launches: this instruction-heavier kernel runs 10-25 % slower right after a pause)
     t31f = event_time(lambda: ops.synth_forward([p31], [q31], 4.0, soft=True, out_W=W), 20, warm=20)
-    t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 20, warm=20)
-    for nm, tt, bpr in (("aq::synth_fwd_kernel<8, 3, false, false, false> (L = 31)", t31f, 4 * L31 + 4), ("aq::synth_bwd_kernel<8, 3, false, false> (L = 31)", t31b, 8 * L31 + 4)):
+    n31f = last_kernel()
+    # adp_qtz_fix freezes its levels (adp_qtz_fix.py:649-652): its gradient pass asks for no dq; the learned-level form beside it
+    t31b = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, need_dq=[False], out_dp=dp31), 20, warm=20)
+    n31b = last_kernel()
+    t31q = event_time(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31), 20, warm=20)
+    n31q = last_kernel()
+    for nm, tt, bpr, key in ((n31f + " (L = 31)", t31f, 4 * L31 + 4, "synth_fwd_L31"),
+                             (n31b + " (L = 31, frozen levels as in adp_qtz_fix: no dq)", t31b, 8 * L31 + 4, "synth_bwd_L31_no_dq"),
+                             (n31q + " (L = 31, with dq)", t31q, 8 * L31 + 4, "synth_bwd_L31_dq")):
         aa = rows * bpr / tt / 1e9
         more.append({"bound": "hbm", "kernel": nm, "achieved": round(aa, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(aa / HBM_PEAK_GBS, 4),
-                     "bytes_per_row": bpr, "rows_per_launch": rows, "avg_launch_ms": round(tt * 1e3, 4)})
+                     "traffic": tj.get(key + "_bytes_per_launch"), "bytes_per_row": bpr, "rows_per_launch": rows, "avg_launch_ms": round(tt * 1e3, 4)})
     del p31, dp31
     # the same kernel with the Adam update of p_c fused in: p, m, v read and written, 24L+4 bytes per row
     del dp
     m1, m2, stp = torch.zeros_like(p), torch.zeros_like(p), torch.zeros((), device=dev)
     t3 = event_time(lambda: ops.synth_backward_adam([p], [q], 4.0, [dW], [m1], [m2], [stp], 1e-2, wd=1e-3), 10)
     a3 = rows * (24 * L + 4) / t3 / 1e9
-    more.append({"bound": "hbm", "kernel": "aq::synth_bwd_kernel<8, 2, false, true> (Adam update fused)", "achieved": round(a3, 1),
+    more.append({"bound": "hbm", "kernel": last_kernel() + " (Adam update of p_c fused)", "achieved": round(a3, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 4), "traffic": traffic3, "bytes_per_row": 24 * L + 4,
                  "rows_per_launch": rows, "avg_launch_ms": round(t3 * 1e3, 4)})
     del p, dW, W, m1, m2
@@ -181,13 +193,13 @@ def kernel_rooflines(quick):
     w = torch.randn(n, device=dev) * 0.05
     gw = torch.randn(n, device=dev)
     tq = event_time(lambda: ops.tern_forward([w], "twn", decoded=False), 10)
-    more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel<true> + tern_emit_kernel<false, true> + second stages (threshold 0.7*mean|w|, 1-byte codes)",
+    more.append({"bound": "hbm", "kernel": "ternary quantiser, TWN: aq::tern_absstat_kernel + %s + second stages (threshold 0.7*mean|w|, 1-byte codes)" % last_kernel(),
                  "achieved": round(n * 9 / tq / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 9 / tq / 1e9 / HBM_PEAK_GBS, 4),
                  "traffic": traffic_tern if not quick else None, "bytes_per_weight": 9, "weights_per_call": n, "avg_call_ms": round(tq * 1e3, 4), "parity": "unpinned (no reference implementation)"})
     Wp, Wn = [torch.full((1,), 0.1, device=dev)], [torch.full((1,), 0.08, device=dev)]
     st = ops.tern_forward([w], "ttq", Wp=Wp, Wn=Wn)[0]["stats"]
     tb = event_time(lambda: ops.tern_backward([w], [gw], "ttq", stats=[st], Wp=Wp, Wn=Wn), 10)
-    more.append({"bound": "hbm", "kernel": "aq::tern_bwd_kernel<1, true> (TTQ straight-through + scale gradients)", "achieved": round(n * 12 / tb / 1e9, 1),
+    more.append({"bound": "hbm", "kernel": last_kernel() + " (TTQ straight-through + scale gradients)", "achieved": round(n * 12 / tb / 1e9, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * 12 / tb / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_weight": 12, "weights_per_call": n,
                  "avg_call_ms": round(tb * 1e3, 4), "parity": "unpinned (no reference implementation)"})
     del w, gw
@@ -208,13 +220,39 @@ def kernel_rooflines(quick):
             more.append({"bound": "mfma", "kernel": "%s %d->%d k%d s%d %dx%d N=%d (ResNet-18 shape, general kernels; no reference model)" % (
                 name, cin, cout, ks, s, H, H, B18), "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
+    def graph_time(fn, reps=20):
+        """Average duration of fn() inside a replayed HIP graph of `reps` calls (host launch cost excluded)."""
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(st)
+        return event_time(gr.replay, 5, 2) / reps
+
     for D in (64, 512):
         f = torch.randn(1024, D, device=dev)
-        t = event_time(lambda: ops.pkt_kernel_matrix(f), 10)
+        tch = torch.randn(1024, 512, device=dev)
+        t = graph_time(lambda: ops.pkt_kernel_matrix(f))
         fl = 2.0 * 1024 * 1024 * D
-        more.append({"bound": "mfma", "kernel": "PKT cosine-kernel matrix, batch 1024 x %d features (normalise + aq::pkt_gemm_nt_kernel<true>)" % D,
+        more.append({"bound": "mfma", "kernel": "PKT cosine-kernel matrix, batch 1024 x %d features (aq::pkt_gemm_nt_kernel<true>: row normalisation inside the product, "
+                                                "upper triangle computed and mirrored)" % D,
                      "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4),
                      "avg_call_us": round(t * 1e6, 2), "parity": "unpinned (no reference implementation)"})
+        # the distillation loss itself (student 1024 x D against a 1024 x 512 teacher): forward alone, and forward + gradient
+        # (two kernel matrices, row probabilities, divergence; the Jacobian matrix and one more product of 2 * N^2 * D flops)
+        tl = graph_time(lambda: ops.pkt_loss(f, tch, need_grad=False))
+        tg = graph_time(lambda: ops.pkt_loss(f, tch, need_grad=True))
+        flf = 2.0 * 1024 * 1024 * (D + 512)
+        flg = flf + 2.0 * 1024 * 1024 * D
+        for nm, tt, ff in (("PKT loss forward", tl, flf), ("PKT loss forward + d loss / d student", tg, flg)):
+            more.append({"bound": "mfma", "kernel": "%s, batch 1024, student %d / teacher 512 features (aq_pkt_loss: %d launches)" % (nm, D, 3 if tt is tl else 7),
+                         "achieved": round(ff / tt / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": round(ff / tt / 1e12 / FP32_MATRIX_PEAK_TF, 4),
+                         "avg_call_us": round(tt * 1e6, 2), "parity": "unpinned (no reference implementation)"})
     return roof, more
 
 

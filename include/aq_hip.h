@@ -56,6 +56,9 @@ typedef struct aq_seg {
 } aq_seg;
 
 int aq_abi_version(void);
+/* Name, with its template arguments, of the main kernel that the most recent aq_synth_* / aq_tern_* call of this thread
+ * launched ("" before the first): what a benchmark should print next to a timing instead of a literal. */
+const char *aq_last_kernel(void);
 const char *aq_last_error(void);
 
 /* Weight synthesis of nseg layers in one launch (+ one small reduction launch when any sumsq is

@@ -18,7 +18,7 @@ MAX_LEVELS = 128
 STATIC_SCRATCH_BYTES = 2 << 20
 
 EXPORTS = (
-    "aq_abi_version", "aq_last_error", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
+    "aq_abi_version", "aq_last_error", "aq_last_kernel", "aq_synth_fwd", "aq_synth_bwd", "aq_synth_workspace_bytes",
     "aq_conv_fwd", "aq_conv_fwd_codes", "aq_conv_dgrad", "aq_conv_wgrad", "aq_conv_wgrad_workspace_bytes",
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
     "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_partial_group", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
@@ -164,10 +164,16 @@ def lib():
         for name in ("aq_synth_fwd", "aq_synth_bwd", "aq_conv_fwd", "aq_conv_fwd_add", "aq_conv_fwd_codes", "aq_conv_dgrad",
                      "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce"):
             getattr(L, name).restype = i
+        L.aq_last_kernel.restype = C.c_char_p
         if L.aq_abi_version() != ABI_VERSION:
             raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
+
+
+def last_kernel():
+    """Name, with template arguments, of the main kernel the most recent synthesis / ternary call of this thread launched."""
+    return lib().aq_last_kernel().decode()
 
 
 def check(rc):

@@ -10,6 +10,8 @@ namespace aq {
 
 char *error_buffer();           // thread-local, 512 bytes
 int fail(int code, const char *fmt, ...);
+// name (with template arguments) of the main kernel of the most recent call on this thread, for aq_last_kernel()
+void note_kernel(const char *fmt, ...);
 
 inline int check_launch(const char *what)
 {

@@ -49,11 +49,28 @@ __global__ __launch_bounds__(256) void pkt_normalize_kernel(const float *__restr
 // wavefronts owns a 64 x 64 tile, a wavefront 32 x 32 (2 x 2 MFMA tiles).  Operands go from memory (L2: these
 // matrices are a few MB) straight into registers as 16-byte loads of four consecutive k per lane: lane (r, kq)
 // of a 16-row fragment holds k = 16 kb + 4 kq + t in step t, for A and B alike, so the four MFMAs of a k-block
-// cover its 16 k exactly once.  GRAM: the epilogue stores (c + 1) / 2.
+// cover its 16 k exactly once.
+// GRAM: the cosine-kernel matrix K = (xh xh^T + 1) / 2 of the RAW features x (A = B = x), xh = x / (|x| + eps): every
+// lane sums the squares of the operand elements it streams anyway, four lanes complete a row's |x|^2, and the
+// epilogue scales the raw dot product by 1 / ((|x_i| + eps) (|x_j| + eps)) - no normalisation pass, no normalised
+// copy.  blockIdx.z selects one of two feature matrices (student / teacher in one launch); tiles below the diagonal
+// return at once, tiles above it also write their mirror image (the matrix is symmetric bit for bit by construction).
+struct PktGram {
+    const float *x[2];
+    float *K[2];
+    int D[2];
+    float eps;
+};
 template <bool GRAM>
 __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ Cm, int M,
-                                                          int Nc, int K)
+                                                          int Nc, int K, const PktGram gr)
 {
+    if (GRAM) {
+        if (blockIdx.x < blockIdx.y) return;
+        A = B = gr.x[blockIdx.z];
+        Cm = gr.K[blockIdx.z];
+        K = gr.D[blockIdx.z];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
@@ -62,6 +79,7 @@ __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restric
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = pkt_f4{0.f, 0.f, 0.f, 0.f};
+    float ssa[2] = {0.0f, 0.0f}, ssb[2] = {0.0f, 0.0f};  // GRAM: this lane's share of |x|^2 of its two A rows / B rows
     const bool vec = (K & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
     auto load = [&](const float *__restrict__ P, int rows, int row, int k0, float (&v)[4]) {
         const int k = k0 + 4 * kq;
@@ -115,6 +133,15 @@ __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restric
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s0][i][t], bv[s0][j][t], acc[i][j], 0, 0, 0);
+                    if (GRAM) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                ssa[i] = __builtin_fmaf(av[s0][i][t], av[s0][i][t], ssa[i]);
+                                ssb[i] = __builtin_fmaf(bv[s0][i][t], bv[s0][i][t], ssb[i]);
+                            }
+                    }
                 }
             }
         }
@@ -139,6 +166,15 @@ __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restric
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][t], b0[j][t], acc[i][j], 0, 0, 0);
+        if (GRAM) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ssa[i] = __builtin_fmaf(a0[i][t], a0[i][t], ssa[i]);
+                    ssb[i] = __builtin_fmaf(b0[i][t], b0[i][t], ssb[i]);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -149,6 +185,19 @@ __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restric
     }
     }
     // D[row = 4 * (lane >> 4) + q][col = lane & 15]
+    float inva[2] = {1.0f, 1.0f}, invb[2] = {1.0f, 1.0f};
+    if (GRAM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // the four lanes (r, kq = 0..3) complete row r: the same value in all four
+            ssa[i] += __shfl_xor(ssa[i], 16);
+            ssa[i] += __shfl_xor(ssa[i], 32);
+            ssb[i] += __shfl_xor(ssb[i], 16);
+            ssb[i] += __shfl_xor(ssb[i], 32);
+            inva[i] = 1.0f / (__builtin_sqrtf(ssa[i]) + gr.eps);
+            invb[i] = 1.0f / (__builtin_sqrtf(ssb[i]) + gr.eps);
+        }
+    }
+    const bool mirror = GRAM && blockIdx.x != blockIdx.y;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -156,9 +205,14 @@ __global__ __launch_bounds__(256) void pkt_gemm_nt_kernel(const float *__restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = m0 + 16 * i + 4 * kq + q, col = n0 + 16 * j + r;
+                float v = acc[i][j][q];
+                if (GRAM) {
+                    const float ir = __shfl(inva[i], 4 * kq + q);  // lane 4 kq + q holds the A row of this element
+                    v = __builtin_fmaf(v, ir * invb[j], 1.0f) * 0.5f;
+                }
                 if (row < M && col < Nc) {
-                    const float v = acc[i][j][q];
-                    Cm[(long long)row * Nc + col] = GRAM ? (v + 1.0f) * 0.5f : v;
+                    Cm[(long long)row * Nc + col] = v;
+                    if (mirror) Cm[(long long)col * Nc + row] = v;
                 }
             }
 }
@@ -288,18 +342,21 @@ int aq_pkt_loss(const float *student, const float *teacher, int N, int Ds, int D
     float *ns = take((size_t)N * 4), *nt = take((size_t)N * 4), *rs = take((size_t)N * 4), *rt = take((size_t)N * 4);
     float *lrow = take((size_t)N * 4), *crow = take((size_t)N * 4);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pkt_normalize_kernel, dim3(N), dim3(256), 0, st, student, xs, dstudent ? xsT : nullptr, ns, N, Ds, eps);
-    hipLaunchKernelGGL(pkt_normalize_kernel, dim3(N), dim3(256), 0, st, teacher, xt, (float *)nullptr, nt, N, Dt, eps);
-    const dim3 g((N + 63) / 64, (N + 63) / 64);
-    hipLaunchKernelGGL(pkt_gemm_nt_kernel<true>, g, dim3(256), 0, st, xs, xs, Ks, N, N, Ds);
-    hipLaunchKernelGGL(pkt_gemm_nt_kernel<true>, g, dim3(256), 0, st, xt, xt, Kt, N, N, Dt);
+    (void)xt;
+    (void)nt;
+    // both kernel matrices in one launch, straight from the raw features (normalisation inside the product)
+    const dim3 g((N + 63) / 64, (N + 63) / 64, 2);
+    const PktGram gr{{student, teacher}, {Ks, Kt}, {Ds, Dt}, eps};
+    hipLaunchKernelGGL(pkt_gemm_nt_kernel<true>, g, dim3(256), 0, st, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, N, N, 0, gr);
+    // the backward product needs the normalised student features, also transposed
+    if (dstudent) hipLaunchKernelGGL(pkt_normalize_kernel, dim3(N), dim3(256), 0, st, student, xs, xsT, ns, N, Ds, eps);
     hipLaunchKernelGGL(pkt_rows_kernel, dim3(N), dim3(256), 0, st, Ks, Kt, N, eps, rs, rt, lrow, crow);
     hipLaunchKernelGGL(pkt_loss_sum_kernel, dim3(1), dim3(256), 0, st, lrow, N, loss);
     if (dstudent) {
         const long long ne = (long long)N * N;
         hipLaunchKernelGGL(pkt_m_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, Ks, Kt, rs, rt, crow, N, eps, grad_scale, Mm);
         const dim3 g2((Ds + 63) / 64, (N + 63) / 64);
-        hipLaunchKernelGGL(pkt_gemm_nt_kernel<false>, g2, dim3(256), 0, st, Mm, xsT, dxh, N, Ds, N);  // dxh = M xh
+        hipLaunchKernelGGL(pkt_gemm_nt_kernel<false>, g2, dim3(256), 0, st, Mm, xsT, dxh, N, Ds, N, PktGram{});  // dxh = M xh
         hipLaunchKernelGGL(pkt_norm_bwd_kernel, dim3(N), dim3(256), 0, st, xs, dxh, ns, dstudent, Ds, eps);
     }
     return check_launch("aq_pkt_loss");
@@ -312,14 +369,12 @@ int aq_pkt_kernel_matrix(const float *feat, int N, int D, float eps, float *K, v
     using namespace aq;
     AQ_REQUIRE(N >= 1 && N <= 32768 && D >= 1 && D <= (1 << 20), -EINVAL, "aq_pkt_kernel_matrix: bad sizes N=%d D=%d", N, D);
     AQ_REQUIRE(feat && K, -EFAULT, "aq_pkt_kernel_matrix: NULL pointer");
-    const size_t need = pkt_align((size_t)N * D * 4) + pkt_align((size_t)N * 4);
-    AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
-               "aq_pkt_kernel_matrix: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
-    float *xh = static_cast<float *>(workspace);
-    float *nr = reinterpret_cast<float *>(static_cast<char *>(workspace) + pkt_align((size_t)N * D * 4));
+    (void)workspace;
+    (void)workspace_bytes;  // (kept in the signature: earlier versions normalised into it)
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pkt_normalize_kernel, dim3(N), dim3(256), 0, st, feat, xh, (float *)nullptr, nr, N, D, eps);
-    hipLaunchKernelGGL(pkt_gemm_nt_kernel<true>, dim3((N + 63) / 64, (N + 63) / 64), dim3(256), 0, st, xh, xh, K, N, N, D);
+    const PktGram gr{{feat, feat}, {K, K}, {D, D}, eps};
+    hipLaunchKernelGGL(pkt_gemm_nt_kernel<true>, dim3((N + 63) / 64, (N + 63) / 64, 1), dim3(256), 0, st, (const float *)nullptr, (const float *)nullptr,
+                       (float *)nullptr, N, N, 0, gr);
     return check_launch("aq_pkt_kernel_matrix");
 }
 

@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void synth_fwd_kernel(const SegTab tab, const 
 // with step_size = lr/(1-beta1^t), rbc2 = 1/sqrt(1-beta2^t) prepared per layer by adam_prep_kernel.
 // This removes the dp_c round trip through memory: 6 tensor passes (p, m, v read and written) instead
 // of 2 (K2) + 7 (separate Adam).
-template <int G, int MEM, bool EXACT, bool ADAM, int NU = 8>  // NU: as in synth_fwd_kernel
+// DQ = false: no layer of the launch wants the gradient of its levels (adp_qtz_fix freezes them, adp_qtz_fix.py:649-652):
+// the per-lane accumulators of dq, their updates and the closing shuffles are compiled out.
+template <int G, int MEM, bool EXACT, bool ADAM, int NU = 8, bool DQ = true>  // NU: as in synth_fwd_kernel
 __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const float beta, const float wd, const AdamArgs ad)
 {
     static_assert(NU == 8 || (NU == 4 && G == 8), "half batches exist for 8 lanes per row only");
@@ -485,8 +487,10 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                             store_rows_staged<G, true>(am, R0, RPP, L, j, gq, lane, mo, stage, rag_stream);
                             store_rows_staged<G, true>(av, R0, RPP, L, j, gq, lane, vo, stage, rag_stream);
                         }
+                        if constexpr (DQ) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                            for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                        }
                     } else {
                         if (rag) {  // uniform: the rows of this instruction leave as one aligned run (all lanes take part)
                             const long long R0 = row0 + (long long)(ub + u) * RPP;
@@ -507,8 +511,10 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
                                     store_elems<G, MEM>(av, r, L, j, vo);
                                 }
                             }
+                            if constexpr (DQ) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                                for (int k = 0; k < 4; ++k) accq[k] = __builtin_fmaf(s[k], g, accq[k]);
+                            }
                         }
                     }
                 });
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(const SegTab tab, const 
             batch(std::false_type{});
         }
     }
-    if (part) {
+    if (DQ && part) {
 #pragma unroll
         for (int m = G; m < 64; m <<= 1) {
 #pragma unroll
@@ -680,30 +686,34 @@ static void make_plan(const aq_seg *segs, int nseg, bool bwd, Plan &pl)
 
 template <bool BWD>
 static void launch_class(int G, int mem, bool hard, bool exact, const SegTab &tab, int nblocks, float beta, float wd, const AdamArgs *adam,
-                         hipStream_t st, bool codes_only = false, bool half = false)
+                         hipStream_t st, bool codes_only = false, bool half = false, bool no_dq = false)
 {
     const AdamArgs ad = adam ? *adam : AdamArgs{};
 #define AQ_LAUNCH(GG, MM)                                                                                             \
-    if (BWD && half && GG == 8 && MM == 2 && !exact) {                                                              \
+    if (BWD && no_dq && GG == 8 && (MM == 3 || MM == 0) && !exact) { /* frozen levels, ragged rows: adp_qtz_fix */  \
+        constexpr bool RG = (GG == 8 && (MM == 3 || MM == 0));                                                        \
+        if (adam) { note_kernel("aq::synth_bwd_kernel<%d, %d, false, true, 8, false>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true, 8, !RG>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+        else { note_kernel("aq::synth_bwd_kernel<%d, %d, false, false, 8, false>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false, 8, !RG>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+    } else if (BWD && half && GG == 8 && MM == 2 && !exact) {                                                              \
         constexpr int NH = (GG == 8 && MM == 2) ? 4 : 8;                                                              \
-        if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
-        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        if (adam) { note_kernel("aq::synth_bwd_kernel<%d, %d, false, true, 4>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+        else { note_kernel("aq::synth_bwd_kernel<%d, %d, false, false, 4>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
     } else if (BWD) {                                                                                                 \
-        if (adam && exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
-        else if (adam) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
-        else if (exact) hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
-        else hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); \
+        if (adam && exact) { note_kernel("aq::synth_bwd_kernel<%d, %d, true, true>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+        else if (adam) { note_kernel("aq::synth_bwd_kernel<%d, %d, false, true>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+        else if (exact) { note_kernel("aq::synth_bwd_kernel<%d, %d, true, false>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, true, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
+        else { note_kernel("aq::synth_bwd_kernel<%d, %d, false, false>", GG, MM); hipLaunchKernelGGL((synth_bwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta, wd, ad); } \
     } else if (half && GG == 8 && MM == 2 && !hard && !exact) {                                                      \
         constexpr int NH = (GG == 8 && MM == 2) ? 4 : 8;                                                              \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta); \
+        { note_kernel("aq::synth_fwd_kernel<%d, %d, false, false, false, 4>", GG, MM); hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false, false, NH>), dim3(nblocks), dim3(256), 0, st, tab, beta); } \
     } else if (hard && codes_only)                                                                                    \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); \
+        { note_kernel("aq::synth_fwd_kernel<%d, %d, true, true, true>", GG, MM); hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); } \
     else if (hard)                                                                                                    \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);       \
+        { note_kernel("aq::synth_fwd_kernel<%d, %d, true, true>", GG, MM); hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, true, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); }       \
     else if (exact)                                                                                                   \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta);      \
+        { note_kernel("aq::synth_fwd_kernel<%d, %d, false, true>", GG, MM); hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, true>), dim3(nblocks), dim3(256), 0, st, tab, beta); }      \
     else                                                                                                              \
-        hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta);
+        { note_kernel("aq::synth_fwd_kernel<%d, %d, false, false>", GG, MM); hipLaunchKernelGGL((synth_fwd_kernel<GG, MM, false, false>), dim3(nblocks), dim3(256), 0, st, tab, beta); }
 #define AQ_LAUNCH_G(GG)                      \
     if (mem == 2) { AQ_LAUNCH(GG, 2) }       \
     else if (mem == 1) { AQ_LAUNCH(GG, 1) }  \
@@ -771,11 +781,11 @@ static int run(const aq_seg *segs, int nseg, float beta, float wd, unsigned flag
             tab.nseg = 0;
             tab.K = pl.K;
             int nblocks = 0;
-            bool hard = false, wants_w = false;  // wants_w: some layer of the launch asks for W or sum W^2
+            bool hard = false, wants_w = false;  // wants_w: some layer of the launch asks for W or sum W^2 (backward: dq)
             auto flush = [&]() {
                 if (tab.nseg)
                     launch_class<BWD>(G, vec ? (stream_policy ? 2 : 1) : (stream_policy ? 3 : 0), hard, exact, tab, nblocks, beta, wd, adam ? &ad_dev : nullptr, st,
-                                      hard && !wants_w, half_call && vec);
+                                      hard && !wants_w, half_call && vec, BWD && !wants_w);
                 tab.nseg = 0;
                 nblocks = 0;
                 hard = wants_w = false;

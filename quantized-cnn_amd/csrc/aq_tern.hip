@@ -728,13 +728,13 @@ int aq_tern_fwd(const aq_tern_seg *segs, int nseg, int mode, float factor, int t
     launch_levels<2, 1>(tab, st);
     hipLaunchKernelGGL(tern_delta_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab, factor, threshold_from_max ? 1 : 0);
     if (mode == AQ_TERN_TTQ) {
-        if (tab.nt) hipLaunchKernelGGL((tern_emit_kernel<true, true>), dim3(blocks), dim3(256), 0, st, tab);
-        else hipLaunchKernelGGL((tern_emit_kernel<true, false>), dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) { note_kernel("aq::tern_emit_kernel<true, true>"); hipLaunchKernelGGL((tern_emit_kernel<true, true>), dim3(blocks), dim3(256), 0, st, tab); }
+        else { note_kernel("aq::tern_emit_kernel<true, false>"); hipLaunchKernelGGL((tern_emit_kernel<true, false>), dim3(blocks), dim3(256), 0, st, tab); }
         launch_levels<3, -1>(tab, st);
         hipLaunchKernelGGL(tern_codebook_kernel<true>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else {
-        if (tab.nt) hipLaunchKernelGGL((tern_emit_kernel<false, true>), dim3(blocks), dim3(256), 0, st, tab);
-        else hipLaunchKernelGGL((tern_emit_kernel<false, false>), dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) { note_kernel("aq::tern_emit_kernel<false, true>"); hipLaunchKernelGGL((tern_emit_kernel<false, true>), dim3(blocks), dim3(256), 0, st, tab); }
+        else { note_kernel("aq::tern_emit_kernel<false, false>"); hipLaunchKernelGGL((tern_emit_kernel<false, false>), dim3(blocks), dim3(256), 0, st, tab); }
         launch_levels<3, -1>(tab, st);
         hipLaunchKernelGGL(tern_codebook_kernel<false>, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
         if (decode) hipLaunchKernelGGL(tern_decode_kernel, dim3(blocks), dim3(256), 0, st, tab);
@@ -760,16 +760,16 @@ int aq_tern_bwd(const aq_tern_seg *segs, int nseg, int mode, void *workspace, si
     AQ_REQUIRE(blocks > 0, -E2BIG, "aq_tern_bwd: too many elements for one launch");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == AQ_TERN_TTQ) {
-        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<1, true>), dim3(blocks), dim3(256), 0, st, tab);
-        else hipLaunchKernelGGL((tern_bwd_kernel<1, false>), dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) { note_kernel("aq::tern_bwd_kernel<1, true>"); hipLaunchKernelGGL((tern_bwd_kernel<1, true>), dim3(blocks), dim3(256), 0, st, tab); }
+        else { note_kernel("aq::tern_bwd_kernel<1, false>"); hipLaunchKernelGGL((tern_bwd_kernel<1, false>), dim3(blocks), dim3(256), 0, st, tab); }
         launch_levels<2, -1>(tab, st);
         hipLaunchKernelGGL(tern_scale_grad_kernel, dim3(nseg), dim3(second_stage_threads(tab)), 0, st, tab);
     } else if (mode == AQ_TERN_INQ) {
-        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<2, true>), dim3(blocks), dim3(256), 0, st, tab);
-        else hipLaunchKernelGGL((tern_bwd_kernel<2, false>), dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) { note_kernel("aq::tern_bwd_kernel<2, true>"); hipLaunchKernelGGL((tern_bwd_kernel<2, true>), dim3(blocks), dim3(256), 0, st, tab); }
+        else { note_kernel("aq::tern_bwd_kernel<2, false>"); hipLaunchKernelGGL((tern_bwd_kernel<2, false>), dim3(blocks), dim3(256), 0, st, tab); }
     } else {
-        if (tab.nt) hipLaunchKernelGGL((tern_bwd_kernel<0, true>), dim3(blocks), dim3(256), 0, st, tab);
-        else hipLaunchKernelGGL((tern_bwd_kernel<0, false>), dim3(blocks), dim3(256), 0, st, tab);
+        if (tab.nt) { note_kernel("aq::tern_bwd_kernel<0, true>"); hipLaunchKernelGGL((tern_bwd_kernel<0, true>), dim3(blocks), dim3(256), 0, st, tab); }
+        else { note_kernel("aq::tern_bwd_kernel<0, false>"); hipLaunchKernelGGL((tern_bwd_kernel<0, false>), dim3(blocks), dim3(256), 0, st, tab); }
     }
     return check_launch("aq_tern_bwd");
 }

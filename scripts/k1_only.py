@@ -26,3 +26,17 @@ for _ in range(5):
     ops.tern_forward([w], "twn", decoded=False)
 print("codes-only alg bytes", rows * 133, "ternary quantise alg bytes", w.numel() * 9)
 torch.cuda.synchronize()
+# 31 levels (adp_qtz_fix: 124-byte rows): forward, gradient without dq (frozen levels) and with dq; exact forward with W + codes
+p31 = p.view(-1)[:rows * 31].view(rows, 31)
+q31 = torch.cat([q[:15], torch.zeros(1, device="cuda"), q[17:]]).contiguous()
+dp31 = [torch.empty_like(p).view(-1)[:rows * 31].view(rows, 31)]
+for _ in range(5):
+    ops.synth_forward([p31], [q31], 4.0, out_W=W)
+for _ in range(5):
+    ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, need_dq=[False], out_dp=dp31)
+for _ in range(5):
+    ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, out_dp=dp31)
+for _ in range(5):
+    ops.synth_forward([p], [q], 4.0, soft=True, codes=True)
+torch.cuda.synchronize()
+print("L = 31 alg bytes fwd", rows * 128, "bwd", rows * 252, "; exact W + codes + q[code] alg bytes", rows * 141)

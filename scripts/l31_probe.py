@@ -31,6 +31,8 @@ for rnd in range(4):
     print("round %d  L31 views     %.3f ms %.0f GB/s" % (rnd, t * 1e3, rows * 252 / t / 1e9), flush=True)
     t = timed(lambda: ops.synth_backward([s31], [q31], 4.0, [dW], 1e-3, out_dp=[sdp31]))
     print("round %d  L31 separate  %.3f ms %.0f GB/s" % (rnd, t * 1e3, rows * 252 / t / 1e9), flush=True)
+    t = timed(lambda: ops.synth_backward([p31], [q31], 4.0, [dW], 1e-3, need_dq=[False], out_dp=[dp31]))
+    print("round %d  L31 views, frozen levels (no dq)  %.3f ms %.0f GB/s" % (rnd, t * 1e3, rows * 252 / t / 1e9), flush=True)
     t = timed(lambda: ops.synth_forward([p31], [q31], 4.0, out_W=[W]))
     print("round %d  L31 K1        %.3f ms %.0f GB/s" % (rnd, t * 1e3, rows * 128 / t / 1e9), flush=True)
 q = torch.tensor([-(2.0 ** -k) for k in range(2, 18)] + [2.0 ** -k for k in range(17, 1, -1)], device="cuda")

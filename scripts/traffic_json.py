@@ -29,8 +29,12 @@ d = {"how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eac
      "rows_per_launch": rows, "L": L}
 for key, needles, alg in (("synth_fwd", ("synth_fwd_kernel<8, 2, false, false, false",), rows * 132),
                           ("synth_fwd_codes_only", ("synth_fwd_kernel<8, 2, true, true, true",), rows * 133),
-                          ("synth_bwd", ("synth_bwd_kernel<8, 2, false, false",), rows * 260),
-                          ("synth_bwd_adam", ("synth_bwd_kernel<8, 2, false, true",), rows * 772)):
+                          ("synth_bwd", ("synth_bwd_kernel<8, 2, false, false, 4",), rows * 260),
+                          ("synth_bwd_adam", ("synth_bwd_kernel<8, 2, false, true",), rows * 772),
+                          ("synth_fwd_exact_W_codes", ("synth_fwd_kernel<8, 2, true, true, false",), rows * 141),
+                          ("synth_fwd_L31", ("synth_fwd_kernel<8, 3, false, false, false",), rows * 128),
+                          ("synth_bwd_L31_no_dq", ("synth_bwd_kernel<8, 3, false, false, 8, false",), rows * 252),
+                          ("synth_bwd_L31_dq", ("synth_bwd_kernel<8, 3, false, false, 8, true",), rows * 252)):
     f, w = pick(F, *needles), pick(Wr, *needles)
     d[key + "_FETCH_SIZE_raw_bytes"], d[key + "_WRITE_SIZE_raw_bytes"] = f, w
     d[key + "_bytes_per_launch"], d[key + "_algorithmic_bytes"] = 2 * f + w, alg
