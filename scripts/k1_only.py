@@ -39,4 +39,4 @@ for _ in range(5):
 for _ in range(5):
     ops.synth_forward([p], [q], 4.0, soft=True, codes=True)
 torch.cuda.synchronize()
-print("L = 31 alg bytes fwd", rows * 128, "bwd", rows * 252, "; exact W + codes + q[code] alg bytes", rows * 141)
+print("L = 31 alg bytes fwd", rows * 128, "bwd", rows * 252, "; exact W + codes + q[code] alg bytes", rows * 137)

@@ -31,7 +31,7 @@ for key, needles, alg in (("synth_fwd", ("synth_fwd_kernel<8, 2, false, false, f
                           ("synth_fwd_codes_only", ("synth_fwd_kernel<8, 2, true, true, true",), rows * 133),
                           ("synth_bwd", ("synth_bwd_kernel<8, 2, false, false, 4",), rows * 260),
                           ("synth_bwd_adam", ("synth_bwd_kernel<8, 2, false, true",), rows * 772),
-                          ("synth_fwd_exact_W_codes", ("synth_fwd_kernel<8, 2, true, true, false",), rows * 141),
+                          ("synth_fwd_exact_W_codes", ("synth_fwd_kernel<8, 2, true, true, false",), rows * 137),
                           ("synth_fwd_L31", ("synth_fwd_kernel<8, 3, false, false, false",), rows * 128),
                           ("synth_bwd_L31_no_dq", ("synth_bwd_kernel<8, 3, false, false, 8, false",), rows * 252),
                           ("synth_bwd_L31_dq", ("synth_bwd_kernel<8, 3, false, false, 8, true",), rows * 252)):
