@@ -348,13 +348,16 @@ int aq_adam_step(const aq_adam_item *items, int nitems, double lr, double beta1,
  *   out[0] = mean cross entropy, out[1] = l2_reg * (sum sumsq_a[0..na) + sum sumsq_b[0..nb)), out[2] = their sum;
  *   dlogits [N, C] (may be NULL) = grad_scale * d out[0] / d logits = grad_scale * (softmax - onehot) / N
  *   (grad_scale = 1 / world size lets a data-parallel job SUM its gradients into the mean without a scaling
- *   pass).  A label outside [0, C) makes out[0] NaN. */
+ *   pass).  A label outside [0, C) makes out[0] NaN.  Heads of more than 16384 logits (ImageNet-shaped) run one
+ *   workgroup per image and pass the per-image terms through `workspace` (aq_ce_loss_workspace_bytes(N, C) bytes;
+ *   0 for small heads, workspace may then be NULL). */
 size_t aq_sumsq_workspace_bytes(const long long *sizes, int n);
 int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *out, void *workspace, size_t workspace_bytes,
              void *stream);
+size_t aq_ce_loss_workspace_bytes(int N, int C);
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na,
                const float *sumsq_b, int nb, float l2_reg, float grad_scale, float *dlogits, float *out,
-               void *stream);
+               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Ternary and power-of-two quantisers of the papers the reference cites (README.md:3-29) -----------------
  * The reference's scripts hold no implementation of them (only the citations and, in the file headers

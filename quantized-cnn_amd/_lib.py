@@ -23,7 +23,7 @@ EXPORTS = (
     "aq_linear_fwd", "aq_linear_bwd", "aq_conv_fwd_add", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_bn_workspace_bytes",
     "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_partial_group", "aq_conv_wgrad_reduce", "aq_synth_bwd_adam",
     "aq_packed_bytes", "aq_pack_codes", "aq_unpack_codes", "aq_augment_batch", "aq_absmax", "aq_bn_relu_pool_fwd", "aq_bn_relu_pool_bwd",
-    "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_sumsq_workspace_bytes", "aq_ce_loss",
+    "aq_bnconv_supported", "aq_bnconv_fwd", "aq_bnconv_wgrad_partial", "aq_sumsq", "aq_sumsq_workspace_bytes", "aq_ce_loss", "aq_ce_loss_workspace_bytes",
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
     "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
@@ -144,7 +144,9 @@ def lib():
         L.aq_sumsq.argtypes = [C.POINTER(vp), C.POINTER(C.c_longlong), i, vp, vp, sz, vp]
         L.aq_sumsq_workspace_bytes.argtypes = [C.POINTER(C.c_longlong), i]
         L.aq_sumsq_workspace_bytes.restype = sz
-        L.aq_ce_loss.argtypes = [vp, vp, i, i, vp, i, vp, i, f, f, vp, vp, vp]
+        L.aq_ce_loss.argtypes = [vp, vp, i, i, vp, i, vp, i, f, f, vp, vp, vp, sz, vp]
+        L.aq_ce_loss_workspace_bytes.argtypes = [i, i]
+        L.aq_ce_loss_workspace_bytes.restype = sz
         L.aq_sumsq.restype = L.aq_ce_loss.restype = i
         L.aq_tern_workspace_bytes.argtypes = [C.POINTER(AqTernSeg), i]
         L.aq_tern_workspace_bytes.restype = sz

@@ -106,6 +106,57 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
     }
 }
 
+// Many classes or images (ImageNet-shaped heads: 32 x 1000 logits): one workgroup per image computes that image's
+// log-sum-exp, its gradient row and its loss term; ce_finish_kernel sums the terms in a fixed order and assembles
+// {ce, reg, loss} as ce_loss_kernel does.  Fixed halving trees throughout: deterministic.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float *__restrict__ logits, const long long *__restrict__ labels, int N, int C,
+                                                      float grad_scale, float *__restrict__ dlogits, float *__restrict__ rowloss)
+{
+    __shared__ float sh[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float *x = logits + (size_t)r * C;
+    float m = -__builtin_inff();
+    for (int c = tid; c < C; c += 256) m = fmaxf(m, x[c]);
+    sh[tid] = m;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) sh[tid] = fmaxf(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    m = sh[0];
+    __syncthreads();
+    float se = 0.0f;
+    for (int c = tid; c < C; c += 256) se += expf(x[c] - m);
+    se = block_tree_sum(se, sh);
+    __syncthreads();
+    const float lse = m + logf(se);
+    const long long y = labels[r];
+    const bool ok = y >= 0 && y < C;
+    if (tid == 0) rowloss[r] = ok ? lse - x[ok ? y : 0] : __builtin_nanf("");
+    if (dlogits) {
+        const float rNg = grad_scale / (float)N;
+        for (int c = tid; c < C; c += 256) dlogits[(size_t)r * C + c] = (expf(x[c] - lse) - ((long long)c == y ? 1.0f : 0.0f)) * rNg;
+    }
+}
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict__ rowloss, int N, const float *__restrict__ ssa, int na,
+                                                        const float *__restrict__ ssb, int nb, float l2_reg, float *__restrict__ out)
+{
+    __shared__ float sh[256];
+    float part = 0.0f;
+    for (int r = threadIdx.x; r < N; r += 256) part += rowloss[r];
+    const float tot = block_tree_sum(part, sh);
+    if (threadIdx.x == 0) {
+        float ss = 0.0f;
+        for (int i = 0; i < nb; ++i) ss += ssb[i];
+        for (int i = 0; i < na; ++i) ss += ssa[i];
+        const float ce = tot / (float)N, reg = l2_reg * ss;
+        out[0] = ce;
+        out[1] = reg;
+        out[2] = ce + reg;
+    }
+}
+constexpr long long CE_ONE_WORKGROUP = 16384;  // logits up to this many elements: the single-workgroup kernel (ResNet-20: 128 x 10)
+
 } // namespace aq
 
 extern "C" {
@@ -158,14 +209,25 @@ int aq_sumsq(const float *const *tensors, const long long *sizes, int n, float *
     return 0;
 }
 
+size_t aq_ce_loss_workspace_bytes(int N, int C) { return (long long)N * C > aq::CE_ONE_WORKGROUP ? (size_t)N * sizeof(float) : 0; }
+
 int aq_ce_loss(const float *logits, const long long *labels, int N, int C, const float *sumsq_a, int na, const float *sumsq_b, int nb,
-               float l2_reg, float grad_scale, float *dlogits, float *out, void *stream)
+               float l2_reg, float grad_scale, float *dlogits, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace aq;
     AQ_REQUIRE(N >= 1 && C >= 1 && na >= 0 && nb >= 0, -EINVAL, "aq_ce_loss: bad sizes N=%d C=%d", N, C);
     AQ_REQUIRE(logits && labels && out && (na == 0 || sumsq_a) && (nb == 0 || sumsq_b), -EFAULT, "aq_ce_loss: NULL pointer");
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, N, C, sumsq_a, na, sumsq_b, nb,
-                       l2_reg, grad_scale, dlogits, out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t need = aq_ce_loss_workspace_bytes(N, C);
+    if (need == 0) {
+        hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, st, logits, labels, N, C, sumsq_a, na, sumsq_b, nb, l2_reg, grad_scale, dlogits, out);
+        return check_launch("aq_ce_loss");
+    }
+    AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 3) == 0, -ENOSPC, "aq_ce_loss: workspace of %zu bytes needed for %d x %d logits, %zu given",
+               need, N, C, workspace_bytes);
+    float *rowloss = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(N), dim3(256), 0, st, logits, labels, N, C, grad_scale, dlogits, rowloss);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, rowloss, N, sumsq_a, na, sumsq_b, nb, l2_reg, out);
     return check_launch("aq_ce_loss");
 }
 

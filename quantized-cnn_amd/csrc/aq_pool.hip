@@ -64,6 +64,86 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
     dx[i] = s;
 }
 
+// The same two passes with one image plane per blockIdx.y (32-bit index arithmetic, no 64-bit divisions) and, in the
+// gradient, four consecutive input pixels per thread (one 16-byte store; the up to six window gradients they can
+// receive are loaded once).  Sums in the order of maxpool_bwd_kernel (window rows outer, window columns inner), so both
+// forms give the same bits.  W a multiple of 4.
+__global__ __launch_bounds__(256) void maxpool_fwd_plane_kernel(const float *__restrict__ x, float *__restrict__ y, uint8_t *__restrict__ idx, int H,
+                                                                int W, int OH, int OW)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= OH * OW) return;
+    const int oy = o / OW, ox = o - oy * OW;
+    const float *p = x + (long long)blockIdx.y * H * W;
+    float best = -__builtin_inff();
+    int bi = -1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const float v = p[iy * W + ix];
+            if (bi < 0 || v > best || v != v) {
+                best = v;
+                bi = ky * 3 + kx;
+            }
+        }
+    }
+    const long long q = (long long)blockIdx.y * OH * OW + o;
+    y[q] = best;
+    idx[q] = (uint8_t)bi;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ idx, float *__restrict__ dx, int H,
+                                                               int W, int OH, int OW)
+{
+    const int W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * W4) return;
+    const int iy = t / W4, ix0 = (t - iy * W4) << 2;
+    const float *g = dy + (long long)blockIdx.y * OH * OW;
+    const uint8_t *c = idx + (long long)blockIdx.y * OH * OW;
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, oxb = ix0 >> 1;  // window columns oxb .. oxb + 2 cover the four pixels
+    float gv[2][3];
+    int cv[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = a == 0 ? oy0 : oy1;
+        const bool rowok = oy < OH && (a == 0 || oy1 != oy0);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ox = oxb + b;
+            const bool ok = rowok && ox < OW;
+            gv[a][b] = ok ? g[oy * OW + ox] : 0.0f;
+            cv[a][b] = ok ? (int)c[oy * OW + ox] : -1;
+        }
+    }
+    // pixel ix0 + k lies in window columns oxb + blo[k] .. oxb + bhi[k] (ix0 is a multiple of 4)
+    constexpr int blo[4] = {0, 0, 1, 1}, bhi[4] = {0, 1, 1, 2};
+    float o4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ix = ix0 + k;
+        float s = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = a == 0 ? oy0 : oy1;
+            if (a == 1 && oy1 == oy0) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b < blo[k] || b > bhi[k]) continue;
+                const int kk = (iy - (2 * oy - 1)) * 3 + (ix - (2 * (oxb + b) - 1));
+                if (cv[a][b] == kk) s += gv[a][b];  // (cv = -1 outside the plane)
+            }
+        }
+        o4[k] = s;
+    }
+    typedef float pool_f4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<pool_f4 *>(dx + (long long)blockIdx.y * H * W + iy * W + ix0) = pool_f4{o4[0], o4[1], o4[2], o4[3]};
+}
+
 } // namespace aq
 
 extern "C" {
@@ -77,6 +157,11 @@ int aq_maxpool3s2_fwd(const float *x, float *y, uint8_t *idx, int N, int C, int 
     const int OH = (H + 2 - 3) / 2 + 1, OW = (Wd + 2 - 3) / 2 + 1;
     const long long total = (long long)N * C * OH * OW;
     AQ_REQUIRE((total + 255) / 256 < (1LL << 31), -E2BIG, "aq_maxpool3s2_fwd: tensor too large");
+    if ((long long)N * C <= 65535 && (long long)H * Wd < (1LL << 30)) {
+        hipLaunchKernelGGL(maxpool_fwd_plane_kernel, dim3((unsigned)((OH * OW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, y, idx, H, Wd, OH, OW);
+        return check_launch("aq_maxpool3s2_fwd");
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, idx, total, H, Wd,
                        OH, OW);
     return check_launch("aq_maxpool3s2_fwd");
@@ -91,6 +176,11 @@ int aq_maxpool3s2_bwd(const float *dy, const uint8_t *idx, float *dx, int N, int
     const int OH = (H + 2 - 3) / 2 + 1, OW = (Wd + 2 - 3) / 2 + 1;
     const long long total = (long long)N * C * H * Wd;
     AQ_REQUIRE((total + 255) / 256 < (1LL << 31), -E2BIG, "aq_maxpool3s2_bwd: tensor too large");
+    if ((Wd & 3) == 0 && (long long)N * C <= 65535 && (long long)H * Wd < (1LL << 30) && ((uintptr_t)dx & 15) == 0) {
+        hipLaunchKernelGGL(maxpool_bwd_quad_kernel, dim3((unsigned)((H * (Wd / 4) + 255) / 256), (unsigned)(N * C)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), dy, idx, dx, H, Wd, OH, OW);
+        return check_launch("aq_maxpool3s2_bwd");
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, idx, dx, total, H, Wd,
                        OH, OW);
     return check_launch("aq_maxpool3s2_bwd");

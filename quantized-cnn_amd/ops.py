@@ -638,9 +638,11 @@ def ce_loss(logits, labels, l2_reg=0.0, sumsq_a=None, sumsq_b=None, need_grad=Tr
     d = torch.empty_like(logits) if need_grad else None
     na = 0 if sumsq_a is None else sumsq_a.numel()
     nb = 0 if sumsq_b is None else sumsq_b.numel()
+    nbytes = _lib.lib().aq_ce_loss_workspace_bytes(int(N), int(Cn))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=logits.device) if nbytes else None
     _lib.check(_lib.lib().aq_ce_loss(_lib.ptr(logits, name="logits"), _lib.ptr(labels, torch.int64, "labels"), int(N), int(Cn),
                                      _lib.ptr(sumsq_a, name="sumsq_a"), na, _lib.ptr(sumsq_b, name="sumsq_b"), nb, float(l2_reg),
-                                     float(grad_scale), _lib.ptr(d), _lib.ptr(vals), _lib.stream()))
+                                     float(grad_scale), _lib.ptr(d), _lib.ptr(vals), ws.data_ptr() if ws is not None else None, nbytes, _lib.stream()))
     return vals, d
 
 

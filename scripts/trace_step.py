@@ -3,7 +3,10 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "synth_fwd_kernel" in r["Kernel_Name"]]
+# a step starts with its quantiser launch: the synthesis (adaptive layers), the |w| statistics (TWN / TTQ) or the effective
+# weights (INQ); optional second argument: that kernel's name
+first = sys.argv[2] if len(sys.argv) > 2 else "synth_fwd_kernel"
+idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 50]
 a, b = pairs[-4]
 seg = rows[a:b]

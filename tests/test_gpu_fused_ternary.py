@@ -147,3 +147,26 @@ def test_large_tensor_adam_path_equals_torch_adam():
             assert float((p - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.abs().max()))
             assert float((gr - rr.grad).abs().max()) <= 1e-6 * float(rr.grad.abs().max())  # the regulariser's term was written back
     assert all(float(s) == 3.0 for s in steps)
+
+
+@pytest.mark.parametrize("N,C", [(32, 1000), (7, 3001), (128, 10), (300, 100)])
+def test_cross_entropy_kernels_equal_torch(N, C):
+    """aq_ce_loss in both forms (one workgroup for small heads such as ResNet-20's 128 x 10, one workgroup per image for
+    ImageNet-shaped heads) against torch's cross entropy and its gradient; regulariser value assembled from the sums."""
+    import quantized_cnn_amd.ops as ops
+    g = torch.Generator(device=DEV).manual_seed(N + C)
+    logits = (3.0 * torch.randn(N, C, device=DEV, generator=g)).requires_grad_(True)
+    y = torch.randint(0, C, (N,), device=DEV, generator=g)
+    ssa, ssb = torch.rand(5, device=DEV, generator=g), torch.rand(3, device=DEV, generator=g)
+    vals, d = ops.ce_loss(logits.detach(), y, 0.01, ssa, ssb, grad_scale=0.5)
+    want = torch.nn.functional.cross_entropy(logits, y)
+    want.backward()
+    assert abs(float(vals[0]) - float(want)) <= 2e-6 * abs(float(want))
+    assert abs(float(vals[1]) - 0.01 * float(ssa.sum() + ssb.sum())) <= 1e-6
+    assert abs(float(vals[2]) - float(vals[0]) - float(vals[1])) <= 1e-6
+    assert float((d - 0.5 * logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max()) + 1e-9
+    vals2, d2 = ops.ce_loss(logits.detach(), y, 0.01, ssa, ssb, grad_scale=0.5)
+    assert torch.equal(vals, vals2) and torch.equal(d, d2)
+    bad = y.clone()
+    bad[0] = C
+    assert bool(torch.isnan(ops.ce_loss(logits.detach(), bad, need_grad=False)[0][0]))
