@@ -400,20 +400,23 @@ def cpu_baseline(quick):
     import numpy as np
     from oracle import oracle as O
     O.set_num_threads(nthreads)
-    elems = 25_000_000 if not quick else 2_000_000
+    # sizes of the stand-alone sweep (25 M ... 250 M primary coefficients; the GPU rows above use 250 M); L = 31 at the smallest
+    sizes = (25_000_000, 100_000_000, 250_000_000) if not quick else (2_000_000,)
     sweep = []
-    rs = np.random.RandomState(0)
-    for L in (32, 31):
-        rows = elems // L
-        p = rs.random_sample((rows, L)).astype(np.float32)
-        q = (O.levels_hint(0.3, 32) if L == 32 else O.levels_fix(0.3, 32)).astype(np.float32)
-        dW = rs.standard_normal(rows).astype(np.float32)
-        O.synth_fwd(p[:1000], q, 4.0)
-        t0 = time.perf_counter(); O.synth_fwd(p, q, 4.0, want_idx=False); tf = time.perf_counter() - t0
-        t0 = time.perf_counter(); O.synth_bwd(p, q, 4.0, dW, 1e-3); tb = time.perf_counter() - t0
-        sweep.append({"L": L, "rows": rows, "synth_fwd_GBps": round(rows * (4 * L + 4) / tf / 1e9, 2),
-                      "synth_bwd_GBps": round(rows * (8 * L + 4) / tb / 1e9, 2)})
-    res["quantize_kernels_cpu"] = {"cores": O.num_threads(), "elements": elems, "sweep": sweep}
+    rng = np.random.default_rng(0)
+    for elems in sizes:
+        for L in ((32, 31) if elems == sizes[0] else (32,)):
+            rows = elems // L
+            p = rng.random((rows, L), dtype=np.float32)
+            q = (O.levels_hint(0.3, 32) if L == 32 else O.levels_fix(0.3, 32)).astype(np.float32)
+            dW = rng.standard_normal(rows, dtype=np.float32)
+            O.synth_fwd(p[:1000], q, 4.0)
+            t0 = time.perf_counter(); O.synth_fwd(p, q, 4.0, want_idx=False); tf = time.perf_counter() - t0
+            t0 = time.perf_counter(); O.synth_bwd(p, q, 4.0, dW, 1e-3); tb = time.perf_counter() - t0
+            sweep.append({"L": L, "elements": elems, "rows": rows, "synth_fwd_GBps": round(rows * (4 * L + 4) / tf / 1e9, 2),
+                          "synth_bwd_GBps": round(rows * (8 * L + 4) / tb / 1e9, 2)})
+            del p, dW
+    res["quantize_kernels_cpu"] = {"cores": O.num_threads(), "sweep": sweep}
     return res
 
 

@@ -2346,7 +2346,7 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
             }
             for (int l = 0; l < g1.n; ++l) AQ_REQUIRE(g1.x[l] && g1.dy[l] && g1.part[l], -EFAULT, "aq_conv_wgrad: NULL pointer (layer %d)", l);
             AQ_REQUIRE((long long)cp.grid.x * g1.n < (1LL << 31), -E2BIG, "aq_conv_wgrad: grid too large");
-            wgrad_c16_launch(cp, g1, ks, stride, st);
+            if (int rc = wgrad_c16_launch(cp, g1, ks, stride, st)) return rc;
             *nslab_out = cp.a.nslab;
             return check_launch("aq_conv_wgrad");
         }

@@ -646,8 +646,11 @@ WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int st
     return p;
 }
 
-// launch of a planned conv_wgrad_c16_kernel
-void wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st)
+// launch of a planned conv_wgrad_c16_kernel; 0 or a negative error code.  A tile of more than 64 KB of dynamic LDS (the
+// epilogue tile of the forms with two input-channel groups: 74 752 bytes) needs the kernel's limit raised first: done once
+// per instantiation and size (not per launch), and a refusal - a device without that much LDS per workgroup - is reported
+// with the size asked for instead of surfacing as a generic launch failure.
+int wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st)
 {
     using namespace aq;
     dim3 grid = cp.grid;
@@ -655,7 +658,13 @@ void wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int 
 #define AQ_WC(SS, KK, GG, CC)                                                                                                      \
     {                                                                                                                              \
         auto kern = conv_wgrad_c16_kernel<SS, KK, GG, CC>;                                                                         \
-        if (cp.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds); \
+        static size_t granted = 64 * 1024; /* (per instantiation; one device per process) */                                      \
+        if (cp.lds > granted) {                                                                                                    \
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds); \
+            AQ_REQUIRE(e == hipSuccess, -ENOMEM, "aq_conv_wgrad: the weight-gradient kernel needs %zu bytes of LDS per workgroup: %s", \
+                       cp.lds, hipGetErrorString(e));                                                                              \
+            granted = cp.lds;                                                                                                      \
+        }                                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), cp.lds, st, cp.a, g);                                                            \
     }
 #define AQ_WCC(SS, KK, GG)                        \
@@ -671,5 +680,6 @@ void wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int 
     }
 #undef AQ_WCC
 #undef AQ_WC
+    return 0;
 }
 

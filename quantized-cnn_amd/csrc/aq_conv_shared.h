@@ -133,4 +133,4 @@ struct WgC16Plan {
     size_t lds, ws_bytes;
 };
 WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad, int nlayers = 1);
-void wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st);
+int wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st);

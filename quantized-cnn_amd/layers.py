@@ -160,6 +160,11 @@ def _fused_backward_ok(dW_slot):
     return FUSE_CONV_BACKWARD and _wgrad_deferred is not None and dW_slot is not None and _wgrad_stream is None
 
 
+# Memory: every deferred entry keeps its layer's input x and output gradient dy alive until the owner has run the grouped
+# launches, i.e. until the END of the backward pass (without deferral dy dies as soon as the layer's two gradients are
+# computed).  Peak activation memory therefore grows by the sum of all dy: 0.15 GB for ResNet-20 at batch 128, about
+# 1 GB for ResNet-18 at 224 x 224 / batch 32 - small against 288 GB of HBM, and the price of one launch per layer shape
+# instead of one per layer.  Set DEFER_WGRAD_KERNELS = False to bound it (the first stages then run layer by layer).
 # With deferral on (and no side stream), the first-stage kernels themselves can wait for the end of the backward pass
 # too: the entry then carries (None, slot, None, x, dy, stride, ks, pad) and run_deferred_wgrads launches the layers
 # of one shape together (ops.conv_wgrad_partial_group), e.g. the six 3x3 convolutions of a ResNet-20 stage in one

@@ -459,7 +459,10 @@ def quantize_all(ls):
 
 
 def make_conv(config, in_channel, out_channel, ksize=3, stride=1, padding=1):
-    """Convolution of the flavour config.mode_q names ("twn" | "ttq" | "inq")."""
+    """Convolution of the flavour config.mode_q names ("twn" | "ttq" | "inq").
+    Threshold: config.tern_factor / config.tern_threshold_from_max; the default for BOTH ternary modes is TWN's rule
+    delta = 0.7 * mean|w| (what BASELINE's north star names).  The TTQ paper itself uses delta = t * max|w| with t = 0.05:
+    set tern_threshold_from_max=True, tern_factor=0.05 for the published TTQ threshold."""
     mode_q = getattr(config, "mode_q", "twn")
     if mode_q == "inq":
         return INQConv2d(in_channel, out_channel, ksize, stride, padding, bits=getattr(config, "inq_bits", 5))

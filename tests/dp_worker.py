@@ -148,6 +148,7 @@ def main():
                 if isinstance(m, nn.BatchNorm2d):
                     m.eval()
         dp = DataParallel(model, sync_bn=(a.mode == "gpu_syncbn"))
+        print("rank %d: model broadcast done" % rank, flush=True)
         if a.mode == "gpu_syncbn":
             assert any(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
             try:
@@ -159,8 +160,16 @@ def main():
         X = torch.randn(world * 4, 3, 32, 32, generator=g)
         Y = torch.randint(0, 10, (world * 4,), generator=g)
         x, y = X[rank * 4:(rank + 1) * 4].cuda(), Y[rank * 4:(rank + 1) * 4].cuda()
+        print("rank %d: graph refusal checked" % rank, flush=True)
         step = FusedTrainStep(model, c, hint, dp=dp, use_graph=False, fuse_adam=False)
-        res["loss"] = float(step(x, y))
+        step._phase_a(x, y)
+        torch.cuda.synchronize()
+        print("rank %d: phase A done" % rank, flush=True)
+        step._comm()
+        torch.cuda.synchronize()
+        print("rank %d: exchange done" % rank, flush=True)
+        step._phase_b()
+        res["loss"] = float(step.loss)
         res["reg"] = float(step.reg)
         res["grads"] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
     else:

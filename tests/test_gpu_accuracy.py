@@ -96,7 +96,7 @@ def test_first_step_is_as_close_to_float64_as_the_reference(golden, variant, bat
             ours["d %s.p_c[:4096]" % n] = named[n + ".p_c"].grad.reshape(-1)[:4096].cpu().numpy()
             ref["d %s.p_c[:4096]" % n] = g[k + "dp0_head_" + n]
             f64["d %s.p_c[:4096]" % n] = grads64[n + ".p_c"].reshape(-1)[:4096]
-        assert len(ours) >= 50
+        assert len(ours) >= 40  # (adp_qtz_fix has no level gradients)
     rows = []
     for name in ours:
         scale = _rms(f64[name])
