@@ -258,6 +258,19 @@ int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma
                         const float *save_mean, const float *save_rstd, int N, int C, int HW, unsigned flags,
                         float *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
                         void *stream);
+
+/* y = relu(batch_norm(x) + add) with batch statistics, and its gradients: the tail of a post-activation residual block
+ * (torchvision's BasicBlock, `out = relu(bn2(conv2(..)) + shortcut)`; the reference's own pre-activation blocks
+ * adp_qtz_fan.py:673-693 add the shortcut after the convolution instead, see aq_conv_fwd_add), so no counterpart in the
+ * reference.  Arguments as aq_bn_relu_fwd / _bwd; `add` has the shape of x.  The backward takes the forward's OUTPUT y
+ * (mask y > 0), writes dx and d loss / d add (the masked gradient). */
+int aq_bn_add_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                       long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, const float *add,
+                       float *y, float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes,
+                       const aq_conv_stats *conv_stats, void *stream);
+int aq_bn_add_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *beta,
+                       const float *save_mean, const float *save_rstd, int N, int C, int HW, float *dx, float *dadd,
+                       float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 size_t aq_bn_workspace_bytes(int N, int C, int HW);
 
 /* `self.convK(F.relu(self.bnK(x)))` of a block (adp_qtz_fan.py:674-676, 690-691) without writing the

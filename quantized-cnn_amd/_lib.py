@@ -27,7 +27,7 @@ EXPORTS = (
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
     "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
-    "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition", "aq_tern_bwd_adam", "aq_inq_effective",
+    "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition", "aq_tern_bwd_adam", "aq_inq_effective", "aq_bn_add_relu_fwd", "aq_bn_add_relu_bwd",
     "aq_pkt_workspace_bytes", "aq_pkt_loss", "aq_pkt_kernel_matrix", "aq_maxpool3s2_fwd", "aq_maxpool3s2_bwd",
 )
 TERN_TWN, TERN_TTQ, TERN_INQ = 0, 1, 2
@@ -167,6 +167,9 @@ def lib():
                      "aq_conv_wgrad", "aq_linear_fwd", "aq_linear_bwd", "aq_bn_relu_fwd", "aq_bn_relu_bwd", "aq_shortcut_fwd", "aq_shortcut_bwd", "aq_conv_wgrad_partial", "aq_conv_wgrad_reduce"):
             getattr(L, name).restype = i
         L.aq_last_kernel.restype = C.c_char_p
+        L.aq_bn_add_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp, vp, sz, vp, vp]
+        L.aq_bn_add_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp]
+        L.aq_bn_add_relu_fwd.restype = L.aq_bn_add_relu_bwd.restype = i
         if L.aq_abi_version() != ABI_VERSION:
             raise ImportError("libaq_hip.so ABI %d != binding ABI %d: rebuild" % (L.aq_abi_version(), ABI_VERSION))
         _lib = L

@@ -111,6 +111,9 @@ struct BnApplyArgs {
     // (adp_qtz_fan.py:669-671): [N, sCs, H/2, sW/2] with x's channel c at c + sfront, zeros elsewhere
     float *sout;
     int sW, sfront, sCs;
+    // add != NULL (kernel instantiated with ADD): y = relu(batch_norm(x) + add), the tail of a post-activation residual
+    // block (torchvision's BasicBlock: out = relu(bn2(conv2(..)) + shortcut))
+    const float *add;
 };
 
 // first wavefront of a block: channel statistics -> sc[0] = scale, sc[1] = shift; block 0 of the channel
@@ -130,7 +133,7 @@ __device__ inline void bn_finalize(const BnApplyArgs &a, const BnGeom &g, int c,
     __syncthreads();
 }
 
-template <int VEC, bool RELU, bool SHORT>
+template <int VEC, bool RELU, bool SHORT, bool ADD = false>
 __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
 {
     __shared__ float sc[2];
@@ -168,9 +171,12 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(BnApplyArgs a, BnGeom g)
     bn_finalize(a, g, c, sc);
     const float scale = sc[0], shift = sc[1];
     auto apply = [&](Vec<VEC> v, size_t o) {
+        Vec<VEC> r;
+        if (ADD) r = Vec<VEC>::load(a.add + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float t = __builtin_fmaf(v[j], scale, shift);
+            float t = __builtin_fmaf(v[j], scale, shift);
+            if (ADD) t += r[j];
             v[j] = RELU ? fmaxf(t, 0.0f) : t;
         }
         v.store(a.y + o);
@@ -214,9 +220,13 @@ struct BnBwdArgs {
     // shortcut (adp_qtz_fan.py:669-671), shape [N, pool_Cs, H/2, W/2] with x's channel c at c + pool_front; the
     // gradient it sends to x[n, c, y, x'] is a quarter of its element [n, c + pool_front, y/2, x'/2]
     int pool_W, pool_front, pool_Cs;
+    // kernels instantiated with YM: the forward was y = relu(batch_norm(x) + add); the ReLU's mask is y > 0 (ymask = y), and
+    // the masked gradient, which is also d loss / d add, is written to gout
+    const float *ymask;
+    float *gout;
 };
 
-template <int VEC, bool RELU>
+template <int VEC, bool RELU, bool YM = false>
 __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(BnBwdArgs a, BnGeom g)
 {
     __shared__ float sh[4];
@@ -237,9 +247,11 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(BnBwdArgs a, BnGeom
             d = Vec<VEC>::load(a.dy + o);
         }
         auto v = Vec<VEC>::load(a.x + o);
+        Vec<VEC> ym;
+        if (YM) ym = Vec<VEC>::load(a.ymask + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const bool live = !RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f;
+            const bool live = YM ? ym[j] > 0.0f : (!RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f);
             const float gq = live ? d[j] : 0.0f;
             s1 += gq;
             s2 = __builtin_fmaf(gq, (v[j] - mean) * rstd, s2);
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(BnBwdArgs a, BnGeom
     if (threadIdx.x == 0) a.part[c * g.S + s] = make_float2(s1, s2);
 }
 
-template <int VEC, bool RELU, bool RES>
+template <int VEC, bool RELU, bool RES, bool YM = false>
 __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom g)
 {
     __shared__ float sc[2];
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
                 r = Vec<VEC>::load(a.res + o);
             }
         }
+        if (YM) r = Vec<VEC>::load(a.ymask + o);  // (never together with RES: r carries y)
     };
     Vec<VEC> pd[BN_PRE], pv[BN_PRE], pr[BN_PRE];
     size_t po[BN_PRE];
@@ -322,14 +335,16 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a, BnGeom 
     auto apply = [&](Vec<VEC> d, Vec<VEC> v, Vec<VEC> r, size_t o) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const bool live = !RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f;
+            const bool live = YM ? r[j] > 0.0f : (!RELU || __builtin_fmaf(v[j], scale, shift) > 0.0f);
             const float gq = live ? d[j] : 0.0f;
             const float xh = (v[j] - mean) * rstd;
             float t = scale * ((gq - k1) - xh * k2);
             if (RES) t += r[j];
             d[j] = t;
+            if (YM) r[j] = gq;
         }
         d.store(a.dx + o);
+        if (YM) r.store(a.gout + o);
     };
 #pragma unroll
     for (int u = 0; u < BN_PRE; ++u)
@@ -373,7 +388,7 @@ size_t aq_bn_workspace_bytes(int N, int C, int HW)
 static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                        long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, unsigned flags, float *y,
                        float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream,
-                       bool pool, float *sout = nullptr, int sW = 0, int sfront = 0, int sback = 0)
+                       bool pool, float *sout = nullptr, int sW = 0, int sfront = 0, int sback = 0, const float *add = nullptr)
 {
     using namespace aq;
     const bool eval = flags & AQ_BN_EVAL, relu = flags & AQ_BN_RELU;
@@ -383,7 +398,7 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
     AQ_REQUIRE((flags & ~(AQ_BN_RELU | AQ_BN_EVAL)) == 0, -EINVAL, "aq_bn_relu_fwd: unknown flags 0x%x", flags);
     BnGeom g = bn_geom(N, C, HW);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(y);
+    const bool vec = HW % 4 == 0 && aligned16(x) && aligned16(y) && (!add || aligned16(add));
     if (eval) {
         AQ_REQUIRE(running_mean && running_var, -EFAULT, "aq_bn_relu_fwd: evaluation mode needs the running statistics");
     } else if (cs) {
@@ -407,7 +422,7 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
         launch_bn_stats(x, static_cast<float2 *>(workspace), g, st);
     }
     BnApplyArgs a{x, y, BnStatsIn{static_cast<const float2 *>(workspace), gamma, beta, running_mean, running_var, num_batches_tracked,
-                                  save_mean, save_rstd, eps, momentum}, eval ? 1 : 0, sout, sW, sfront, C + sfront + sback};
+                                  save_mean, save_rstd, eps, momentum}, eval ? 1 : 0, sout, sW, sfront, C + sfront + sback, add};
     const dim3 grid(g.S2, sout ? C + sfront + sback : C);
     AQ_REQUIRE(grid.y <= 65535, -E2BIG, "aq_bn_relu_fwd: more than 65535 channels");
     if (pool) {
@@ -415,6 +430,11 @@ static int bn_fwd_impl(const float *x, const float *gamma, const float *beta, fl
         if (relu) hipLaunchKernelGGL((bn_apply_pool_kernel<true>), pgrid, dim3(BN_T), 0, st, a, g);
         else hipLaunchKernelGGL((bn_apply_pool_kernel<false>), pgrid, dim3(BN_T), 0, st, a, g);
         return check_launch("aq_bn_relu_pool_fwd");
+    }
+    if (add) {  // (with the ReLU; the entry point checks)
+        if (vec) hipLaunchKernelGGL((bn_apply_kernel<4, true, false, true>), grid, dim3(BN_T), 0, st, a, g);
+        else hipLaunchKernelGGL((bn_apply_kernel<1, true, false, true>), grid, dim3(BN_T), 0, st, a, g);
+        return check_launch("aq_bn_add_relu_fwd");
     }
     if (sout) {  // the variant that also writes the shortcut is a kernel of its own: the common one stays lean
         if (vec && relu) hipLaunchKernelGGL((bn_apply_kernel<4, true, true>), grid, dim3(BN_T), 0, st, a, g);
@@ -460,7 +480,7 @@ int aq_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, f
 static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, const float *gamma, const float *beta, const float *save_mean,
                        const float *save_rstd, const float *res, int N, int C, int HW, unsigned flags, float *dx, float *dgamma, float *dbeta,
                        void *workspace, size_t workspace_bytes, const aq_conv_stats *cs, void *stream, int pool_W = 0, int pool_front = 0,
-                       int pool_Cs = 0)
+                       int pool_Cs = 0, const float *ymask = nullptr, float *gout = nullptr)
 {
     using namespace aq;
     if (int rc = check_dims("aq_bn_relu_bwd", N, C, HW, true)) return rc;
@@ -483,9 +503,20 @@ static int bn_bwd_impl(const float *dy, const float *dpool, const float *x, cons
     const bool relu = flags & AQ_BN_RELU;
     // (a vector of four stays inside one image row when the pooled shortcut gradient is addressed)
     const bool vec = HW % 4 == 0 && aligned16(x) && (!dy || aligned16(dy)) && aligned16(dx) && (!res || pool_W > 0 || aligned16(res)) &&
-                     (pool_W == 0 || pool_W % 4 == 0);
-    BnBwdArgs a{dpool, dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta, pool_W, pool_front, pool_Cs};
+                     (pool_W == 0 || pool_W % 4 == 0) && (!ymask || (aligned16(ymask) && aligned16(gout)));
+    BnBwdArgs a{dpool, dy, x, res, dx, static_cast<float2 *>(workspace), gamma, beta, save_mean, save_rstd, dgamma, dbeta, pool_W, pool_front, pool_Cs,
+                ymask, gout};
     const dim3 g1(g.S, C), g2(g.S2, C);
+    if (ymask) {
+        if (vec) {
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true, true>), g1, dim3(BN_T), 0, st, a, g);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true, false, true>), g2, dim3(BN_T), 0, st, a, g);
+        } else {
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true, true>), g1, dim3(BN_T), 0, st, a, g);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true, false, true>), g2, dim3(BN_T), 0, st, a, g);
+        }
+        return check_launch("aq_bn_add_relu_bwd");
+    }
 #define AQ_BN_BWD(V, R)                                                                                        \
     {                                                                                                          \
         if (!cs) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, R>), g1, dim3(BN_T), 0, st, a, g);                \
@@ -518,6 +549,24 @@ int aq_bn_relu_bwd_shortcut(const float *dy, const float *x, const float *gamma,
                "aq_bn_relu_bwd_shortcut: bad sizes H=%d W=%d pad=%d,%d", H, Wd, pad_front, pad_back);
     return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, dshort, N, C, H * Wd, flags, dx, dgamma, dbeta, workspace, workspace_bytes,
                        dgrad_sums, stream, Wd, pad_front, C + pad_front + pad_back);
+}
+
+int aq_bn_add_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                       long long *num_batches_tracked, int N, int C, int HW, float eps, float momentum, const float *add, float *y,
+                       float *save_mean, float *save_rstd, void *workspace, size_t workspace_bytes, const aq_conv_stats *conv_stats, void *stream)
+{
+    AQ_REQUIRE(add, -EFAULT, "aq_bn_add_relu_fwd: NULL add");
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, N, C, HW, eps, momentum, AQ_BN_RELU, y, save_mean, save_rstd,
+                       workspace, workspace_bytes, conv_stats, stream, false, nullptr, 0, 0, 0, add);
+}
+
+int aq_bn_add_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *beta, const float *save_mean,
+                       const float *save_rstd, int N, int C, int HW, float *dx, float *dadd, float *dgamma, float *dbeta, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    AQ_REQUIRE(dy && y && dadd, -EFAULT, "aq_bn_add_relu_bwd: NULL pointer");
+    return bn_bwd_impl(dy, nullptr, x, gamma, beta, save_mean, save_rstd, nullptr, N, C, HW, AQ_BN_RELU, dx, dgamma, dbeta, workspace, workspace_bytes,
+                       nullptr, stream, 0, 0, 0, y, dadd);
 }
 
 int aq_bn_relu_pool_bwd(const float *dpooled, const float *x, const float *gamma, const float *beta, const float *save_mean,

@@ -266,6 +266,36 @@ class _BnRelu(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class _BnAddRelu(torch.autograd.Function):
+    """y = relu(batch_norm(x) + add) with batch statistics as one kernel each way (plus the statistics / reduction passes):
+    the tail of a post-activation residual block.  The backward pass takes the ReLU's mask from the saved OUTPUT and
+    hands the masked gradient to `add` (the shortcut branch)."""
+
+    @staticmethod
+    def forward(ctx, x, add, gamma, beta, bn, conv_stats):
+        x, add = x.contiguous(), add.contiguous()
+        y, mean, rstd = ops.bn_add_relu_forward(x, add, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                                bn.momentum, conv_stats=conv_stats)
+        ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dadd, dg, db = ops.bn_add_relu_backward(dy.contiguous(), x, y, gamma, beta, mean, rstd)
+        return dx, dadd, dg, db, None, None
+
+
+def bn_add_relu(bn, x, add):
+    """relu(bn(x) + add) for an nn.BatchNorm2d module in its usual training configuration on the fused kernels; anything else
+    (evaluation mode, SyncBatchNorm, no affine parameters) through bn_relu and stock operators."""
+    usual = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.weight is not None and bn.momentum is not None
+             and (bn.training or bn.running_mean is None) and not isinstance(bn, nn.SyncBatchNorm) and add.shape == x.shape and add.dtype == x.dtype)
+    if usual:
+        return _BnAddRelu.apply(x, add, bn.weight, bn.bias, bn, _stats_of(x))
+    return F.relu(bn_relu(bn, x, relu=False) + add)
+
+
 def bn_relu_pool(bn, pool, x):
     """`out = F.relu(bn(x)); out = pool(out)` (adp_qtz_fan.py:730-731) -> (N, C, 1, 1).  When the pool is
     an average over the whole plane (nn.AvgPool2d(8) on the 8x8 map of ResNet-20) the pair runs as one

@@ -461,6 +461,46 @@ def bn_relu_backward(dy, x, gamma, beta, save_mean, save_rstd, res=None, relu=Tr
     return dx, dg, db
 
 
+def bn_add_relu_forward(x, add, gamma, beta, running_mean, running_var, num_batches_tracked, eps=1e-5, momentum=0.1, conv_stats=None):
+    """y = relu(batch_norm(x) + add) with batch statistics (the tail of a post-activation residual block) in one launch
+    (plus the statistics pass unless conv_stats carries them) -> (y, save_mean, save_rstd); running statistics updated."""
+    N, Cn, HW = _bn_dims(x)
+    if tuple(add.shape) != tuple(x.shape):
+        raise ValueError("bn_add_relu_forward: add %s must have the shape of x %s" % (tuple(add.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    mean = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    if conv_stats is not None:
+        ws, desc = conv_stats[0], C.byref(conv_stats[1])
+        nbytes = ws.numel()
+    else:
+        nbytes, desc = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW), None
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_bn_add_relu_fwd(
+        _lib.ptr(x, name="x"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"), _lib.ptr(running_mean, name="running_mean"),
+        _lib.ptr(running_var, name="running_var"), _lib.ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), N, Cn, HW,
+        float(eps), float(momentum), _lib.ptr(add, name="add"), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), ws.data_ptr(), nbytes, desc,
+        _lib.stream()))
+    return y, mean, rstd
+
+
+def bn_add_relu_backward(dy, x, y, gamma, beta, save_mean, save_rstd):
+    """-> (dx, dadd, dgamma, dbeta) of bn_add_relu_forward; y is the forward's output (its sign is the ReLU's mask)."""
+    N, Cn, HW = _bn_dims(x)
+    if dy.shape != x.shape or y.shape != x.shape:
+        raise ValueError("bn_add_relu_backward: dy / y must have the shape of x %s" % (tuple(x.shape),))
+    dx, dadd = torch.empty_like(x), torch.empty_like(x)
+    dg = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().aq_bn_workspace_bytes(N, Cn, HW)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().aq_bn_add_relu_bwd(
+        _lib.ptr(dy, name="dy"), _lib.ptr(x, name="x"), _lib.ptr(y, name="y"), _lib.ptr(gamma, name="weight"), _lib.ptr(beta, name="bias"),
+        _lib.ptr(save_mean, name="save_mean"), _lib.ptr(save_rstd, name="save_rstd"), N, Cn, HW, _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dg),
+        _lib.ptr(db), ws.data_ptr(), nbytes, _lib.stream()))
+    return dx, dadd, dg, db
+
+
 # -------------------------------------------------------------------------------------- max pool
 
 def maxpool3s2_forward(x):

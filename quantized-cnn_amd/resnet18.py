@@ -65,10 +65,15 @@ class BasicBlock(nn.Module):
             self.bn_down = nn.BatchNorm2d(cout)
 
     def forward(self, x):
-        out = layers.bn_relu(self.bn1, self.conv1(x))
-        out = layers.bn_relu(self.bn2, self.conv2(out), relu=False)
-        sc = x if self.down is None else layers.bn_relu(self.bn_down, self.down(x), relu=False)
-        return F.relu(out + sc)
+        if self.down is None:
+            # identity shortcut: conv1 hands its input through, so that the gradient arriving over the shortcut is added
+            # in conv1's input-gradient kernel instead of by a separate accumulation launch
+            out, sc = self.conv1(x, split=True)
+        else:
+            out, sc = self.conv1(x), layers.bn_relu(self.bn_down, self.down(x), relu=False)
+        out = layers.bn_relu(self.bn1, out)
+        # relu(bn2(conv2(out)) + shortcut) as one kernel (and one in the backward pass)
+        return layers.bn_add_relu(self.bn2, self.conv2(out), sc)
 
 
 class ResNet18(nn.Module):

@@ -420,6 +420,8 @@ class INQConv2d(nn.Module):
                 z = layers.bn_relu(bn, x)
         else:
             z = x
+        if bn is None and split is True and torch.is_grad_enabled():
+            return layers.conv3x3(z, w, self.stride, slot, res, stats=self.training and usual, split=True, pad=self.padding)
         y = layers.conv3x3(z, w, self.stride, slot, res, stats=self.training and usual and torch.is_grad_enabled(), pad=self.padding)
         if isinstance(split, tuple):
             return y, layers._Shortcut.apply(xs, *split)

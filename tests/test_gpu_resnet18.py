@@ -202,3 +202,28 @@ def test_max_pool_kernels_equal_torch(shape):
     yn, yt = ops.maxpool3s2_forward(xn)[0], torch.nn.functional.max_pool2d(xn, 3, 2, 1)
     assert torch.equal(torch.isnan(yn), torch.isnan(yt)) and torch.equal(yn[~torch.isnan(yn)], yt[~torch.isnan(yt)])
     assert max_pool_3s2(torch.nn.MaxPool2d(2, 2), xn[:, :, :4, :4].nan_to_num()).shape == (1, 1, 2, 2)  # other pools: stock operator
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 56, 56), (3, 5, 7, 9), (2, 16, 8, 8), (8, 128, 4, 4)])
+def test_bn_add_relu_equals_stock_operators(shape):
+    """layers.bn_add_relu, the tail of a post-activation block as one kernel each way, against relu(batch_norm(x) + add) on
+    torch's operators: output, running statistics, and the gradients of x, add, weight and bias."""
+    import quantized_cnn_amd.layers as layers
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(shape, device=DEV, generator=g)
+    add = torch.randn(shape, device=DEV, generator=g)
+    dy = torch.randn(shape, device=DEV, generator=g)
+    outs = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm2d(shape[1]).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, shape[1]))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, shape[1]))
+        xa, aa = x.clone().requires_grad_(True), add.clone().requires_grad_(True)
+        y = layers.bn_add_relu(bn, xa, aa) if fused else F.relu(bn(xa) + aa)
+        y.backward(dy)
+        outs.append((y.detach(), xa.grad, aa.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    names = ("y", "dx", "dadd", "dweight", "dbias", "running_mean", "running_var")
+    for n, a, b in zip(names, outs[0], outs[1]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3), (n, float((a - b).abs().max()), float(b.abs().max()))
+    assert torch.equal(outs[0][2] != 0, outs[1][2] != 0) or float(((outs[0][2] != 0) != (outs[1][2] != 0)).float().mean()) < 1e-5
