@@ -6,6 +6,8 @@
 //   chain   : P phases as P kernel launches in one captured graph (the boundary is the hand-off)
 //   fused   : P phases inside ONE launch, separated by a grid barrier (per-XCD counters -> one top counter ->
 //             per-XCD generation word; release fence before arriving, acquire fence after leaving)
+//   fused, leader release : the same barrier, but only the LAST arriver of each XCD runs the release fence (one write-back of
+//             that XCD's L2 per phase instead of one per workgroup); every workgroup still runs the acquire
 // Every spin is bounded: a workgroup that waits longer than ~2 s of wall clock raises an error word and leaves.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,6 +28,7 @@ struct Bar {
 __device__ __forceinline__ unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // returns false on time-out
+template <bool LEADER>
 __device__ bool grid_barrier(Bar *b, unsigned phase, unsigned per_xcd, unsigned nxcd)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wavefront: its stores have left before the barrier
@@ -33,11 +36,17 @@ __device__ bool grid_barrier(Bar *b, unsigned phase, unsigned per_xcd, unsigned 
     bool ok = true;
     if (threadIdx.x == 0) {
         const unsigned xcd = blockIdx.x & 7;  // blocks are dealt round-robin over the XCDs: b and b + 8 share one (speed only)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LEADER) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned arrived = __hip_atomic_fetch_add(&b->xcd_count[xcd * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         const long long t0 = wall_clock64();
         if (arrived == per_xcd * (phase + 1)) {  // last of this XCD: up to the top counter
+            if (LEADER) {  // every workgroup of this XCD has its stores in the XCD's L2: one write-back for all of them
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             const unsigned top = __hip_atomic_fetch_add(&b->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             if (top == nxcd * (phase + 1)) {
                 for (unsigned x = 0; x < 8; ++x) __hip_atomic_store(&b->gen[x * 32], phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -72,16 +81,49 @@ __device__ __forceinline__ void phase_body(const unsigned *src, unsigned *dst, i
 
 __global__ __launch_bounds__(256, 2) void phase_kernel(const unsigned *src, unsigned *dst) { phase_body(src, dst, blockIdx.x); }
 
+template <bool LEADER>
 __global__ __launch_bounds__(256, 2) void fused_kernel(unsigned *a, unsigned *bbuf, Bar *bar, int phases)
 {
     unsigned *src = a, *dst = bbuf;
     for (int p = 0; p < phases; ++p) {
         phase_body(src, dst, blockIdx.x);
         if (p + 1 < phases) {
-            if (!grid_barrier(bar, (unsigned)p, WG / 8, 8)) return;
+            if (!grid_barrier<LEADER>(bar, (unsigned)p, WG / 8, 8)) return;
         }
         unsigned *t = src; src = dst; dst = t;
     }
+}
+
+template <bool LEADER>
+static bool run_fused(const char *name, unsigned *a, unsigned *b, Bar *bar, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int P, int R)
+{
+    std::vector<unsigned> h((size_t)WG * WORDS);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipMemsetAsync(bar, 0, sizeof(Bar), st));
+        CHECK(hipMemsetAsync(a, 0, (size_t)WG * WORDS * 4, st));
+        hipLaunchKernelGGL(fused_kernel<LEADER>, dim3(WG), dim3(T), 0, st, a, b, bar, P);
+    }
+    CHECK(hipStreamSynchronize(st));
+    CHECK(hipMemcpy(h.data(), (P & 1) ? b : a, h.size() * 4, hipMemcpyDeviceToHost));
+    size_t wrong = 0;
+    for (size_t i = 0; i < h.size(); ++i) wrong += h[i] != (unsigned)P;
+    unsigned err = 0;
+    CHECK(hipMemcpy(&err, &bar->error, 4, hipMemcpyDeviceToHost));
+    printf("%s : result words wrong %zu of %zu, time-out flag %u\n", name, wrong, h.size(), err);
+    if (err) return false;
+    float tot = 0;
+    for (int r = 0; r < R; ++r) {
+        CHECK(hipMemsetAsync(bar, 0, sizeof(Bar), st));
+        CHECK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(fused_kernel<LEADER>, dim3(WG), dim3(T), 0, st, a, b, bar, P);
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+    }
+    printf("%s : one launch of %d phases, %.2f us per phase (%.1f us per launch)\n", name, P, tot * 1e3 / R / P, tot * 1e3 / R);
+    return true;
 }
 
 int main()
@@ -98,7 +140,7 @@ int main()
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     int occ = 0;
-    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fused_kernel, T, 0));
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fused_kernel<false>, T, 0));
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("CUs %d, occupancy API %d blocks per CU -> %d resident, grid %d\n", prop.multiProcessorCount, occ, occ * prop.multiProcessorCount, WG);
@@ -111,7 +153,6 @@ int main()
     for (int p = 0; p < P; ++p) hipLaunchKernelGGL(phase_kernel, dim3(WG), dim3(T), 0, st, (p & 1) ? b : a, (p & 1) ? a : b);
     CHECK(hipStreamEndCapture(st, &g));
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    std::vector<unsigned> h((size_t)WG * WORDS);
     for (int rep = 0; rep < 3; ++rep) {
         CHECK(hipMemsetAsync(a, 0, (size_t)WG * WORDS * 4, st));
         CHECK(hipGraphLaunch(ge, st));
@@ -126,31 +167,8 @@ int main()
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     printf("chain : %d launches per graph, %.2f us per phase (graph of %d phases: %.1f us)\n", P, ms * 1e3 / R / P, P, ms * 1e3 / R);
 
-    // fused
-    for (int rep = 0; rep < 3; ++rep) {
-        CHECK(hipMemsetAsync(bar, 0, sizeof(Bar), st));
-        CHECK(hipMemsetAsync(a, 0, (size_t)WG * WORDS * 4, st));
-        hipLaunchKernelGGL(fused_kernel, dim3(WG), dim3(T), 0, st, a, b, bar, P);
-    }
-    CHECK(hipStreamSynchronize(st));
-    CHECK(hipMemcpy(h.data(), (P & 1) ? b : a, h.size() * 4, hipMemcpyDeviceToHost));
-    size_t wrong = 0;
-    for (size_t i = 0; i < h.size(); ++i) wrong += h[i] != (unsigned)P;
-    unsigned err = 0;
-    CHECK(hipMemcpy(&err, &bar->error, 4, hipMemcpyDeviceToHost));
-    printf("fused : result words wrong %zu of %zu, time-out flag %u\n", wrong, h.size(), err);
-    if (err) return 0;
-    float tot = 0;
-    for (int r = 0; r < R; ++r) {
-        CHECK(hipMemsetAsync(bar, 0, sizeof(Bar), st));
-        CHECK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(fused_kernel, dim3(WG), dim3(T), 0, st, a, b, bar, P);
-        CHECK(hipEventRecord(e1, st));
-        CHECK(hipStreamSynchronize(st));
-        CHECK(hipEventElapsedTime(&ms, e0, e1));
-        tot += ms;
-    }
-    printf("fused : one launch of %d phases, %.2f us per phase (%.1f us per launch)\n", P, tot * 1e3 / R / P, tot * 1e3 / R);
+    if (!run_fused<false>("fused", a, b, bar, st, e0, e1, P, R)) return 0;
+    if (!run_fused<true>("fused, leader release", a, b, bar, st, e0, e1, P, R)) return 0;
     // the phase body alone (what both forms contain): one launch, no dependency
     CHECK(hipEventRecord(e0, st));
     for (int r = 0; r < R; ++r) hipLaunchKernelGGL(phase_kernel, dim3(WG), dim3(T), 0, st, a, b);
