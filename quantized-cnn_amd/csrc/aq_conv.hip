@@ -1776,6 +1776,10 @@ static int launch_gemm(ConvArgs &a, int N, hipStream_t st, const char *who, bool
             const int rc1 = MODE == MODE_DGRAD ? aq_c1_launch_dgrad(a, N, st, who, &taken) : aq_c1_launch_fwd(a, N, st, who, &taken);
             if (taken) return rc1;
         }
+        if (MODE == MODE_FWD) {  // the image stem (RGB, 7x7, stride 2)
+            const int rcs = aq_stem_launch_fwd(a, N, st, who, &taken);
+            if (taken) return rcs;
+        }
         const int rc = launch_c3<MODE>(a, N, st, who, &taken);
         if (taken) return rc;
         return launch_chunked<MODE>(a, N, st, who);
@@ -2148,6 +2152,8 @@ size_t aq_conv_wgrad_workspace_bytes(int N, int Cin, int H, int Wd, int Cout, in
     {
         const WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ksize, stride, pad);
         if (cp.use) need = std::max(need, cp.ws_bytes);
+        const WgStemPlan sp = wgrad_stem_plan(nullptr, N, Cin, H, Wd, Cout, ksize, stride, pad);
+        if (sp.use) need = std::max(need, sp.ws_bytes);
         aq::WgradArgs b = a;
         const WgradBigPlan bp = wgrad_big_plan(b);
         if (bp.use) need = std::max(need, bp.ws_bytes);
@@ -2334,6 +2340,15 @@ static int wgrad_slabs(const float *x, const float *dy, int N, int Cin, int H, i
     if (bn) { a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; }
     a.N = N; a.Cin = Cin; a.H = H; a.Wd = Wd; a.Cout = Cout; a.stride = stride; a.ks = ks; a.pad = pad;
     if (!bn) {
+        const WgStemPlan sp = wgrad_stem_plan(dy, N, Cin, H, Wd, Cout, ks, stride, pad);
+        if (sp.use && grp) return -ENOTSUP;
+        if (sp.use) {
+            AQ_REQUIRE(workspace && workspace_bytes >= sp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", sp.ws_bytes,
+                       workspace_bytes);
+            if (int rc = wgrad_stem_launch(x, dy, static_cast<float *>(workspace), N, Cin, H, Wd, Cout, ks, stride, pad, st)) return rc;
+            *nslab_out = sp.nslab;
+            return check_launch("aq_conv_wgrad");
+        }
         WgC16Plan cp = wgrad_c16_plan(N, Cin, H, Wd, Cout, ks, stride, pad, grp ? std::max(grp->n, grp->total) : 1);
         if (cp.use) {
             AQ_REQUIRE(workspace && workspace_bytes >= cp.ws_bytes, -ENOSPC, "aq_conv_wgrad: workspace too small: need %zu bytes, got %zu", cp.ws_bytes,

@@ -134,3 +134,18 @@ struct WgC16Plan {
 };
 WgC16Plan wgrad_c16_plan(int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad, int nlayers = 1);
 int wgrad_c16_launch(const WgC16Plan &cp, const aq::WgradGroup &g, int ks, int stride, hipStream_t st);
+
+// ---- aq_conv_stem.hip -----------------------------------------------------------------------------------------
+// forward of the image stem (RGB, 7x7, stride 2, output channels a multiple of 64, rows of at most 112 output pixels);
+// *taken = false: not one of its shapes, nothing launched
+int aq_stem_launch_fwd(const aq::ConvArgs &a, int N, hipStream_t st, const char *who, bool *taken);
+// its weight gradient (rows of a multiple of 4 output pixels, dy 16-byte aligned): plan (use = false: not one of its
+// shapes) and launch of the slab kernel
+struct WgStemPlan {
+    bool use;
+    int nslab;
+    size_t ws_bytes;
+};
+WgStemPlan wgrad_stem_plan(const float *dy, int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad);
+int wgrad_stem_launch(const float *x, const float *dy, float *part, int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad,
+                      hipStream_t st);

@@ -19,6 +19,9 @@ DEV = "cuda"
 SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (3, 64, 7, 2, 3, 64, 64, 2),       # ResNet-18 stem at reduced size
     (3, 64, 7, 2, 3, 224, 224, 1),     # ... and at 224 x 224
+    (3, 64, 7, 2, 3, 100, 120, 2),     # stem kernels: rows of 60 output pixels (four pixel tiles, the last one ragged), 50 rows
+    (3, 128, 7, 2, 3, 50, 46, 3),      # ... two groups of 64 output channels; 23 pixels per row (no multiple of 4: general weight gradient)
+    (3, 64, 7, 2, 2, 33, 37, 2),       # ... padding 2, odd sizes
     (64, 64, 3, 1, 1, 56, 56, 1),      # layer1 (fits the tuned kernels)
     (64, 128, 3, 2, 1, 56, 56, 1),     # layer2.0.conv1
     (64, 128, 1, 2, 0, 56, 56, 2),     # layer2.0 projection
