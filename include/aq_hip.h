@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define AQ_ABI_VERSION 12
+#define AQ_ABI_VERSION 13
 #define AQ_MAX_LEVELS 128     /* largest supported number of quantisation levels L */
 #define AQ_MAX_ABS_BETA 64.0f /* |beta| above this is rejected (exp() range of the kernels) */
 /* flags of aq_synth_fwd / aq_synth_bwd */
@@ -429,6 +429,11 @@ int aq_tern_bwd_adam(const aq_tern_seg *segs, int nseg, int mode, double lr, dou
 /* Effective weights of INQ layers: Wt[i] = mask[i] ? W[i] : frozen[i] for every layer in one launch (the weights a
  * layer computes with between INQ stages; frozen = the decoded power-of-two levels). */
 int aq_inq_effective(const aq_tern_seg *segs, int nseg, void *stream);
+/* The same, and sumsq[i] = sum of W[i]^2 over the whole latent tensor from the same pass (the layer's term of the l2
+ * regulariser on "weight" tensors, adp_qtz_fan.py:737-743: aq_sumsq need not read these tensors again); per-wavefront
+ * partials in workspace (aq_tern_workspace_bytes(segs, nseg), 16-byte aligned), added in double in a fixed order. */
+int aq_inq_effective_sumsq(const aq_tern_seg *segs, int nseg, float *sumsq, void *workspace, size_t workspace_bytes,
+                           void *stream);
 /* One INQ partition step, in place: every weight with mask 1 and |w| >= tau is rounded to its power-of-two level
  * (exponents n2..n1, or 0) and its mask cleared; codes (may be NULL): 255 = still trainable, 0 = zero,
  * 1 + 2 * (k - n2) + (w < 0) for +-2^k.  The caller derives tau from the magnitude quantile of the stage and

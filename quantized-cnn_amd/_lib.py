@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQ_HIP_LIB", os.path.join(_HERE, "lib", "libaq_hip.so"))  # override: development builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 FLAG_EXACT = 1
 BN_RELU, BN_EVAL = 1, 2
 MAX_LEVELS = 128
@@ -27,7 +27,7 @@ EXPORTS = (
     "aq_conv_stats_bytes", "aq_conv_fwd_stats", "aq_conv_dgrad_bn_bytes", "aq_conv_dgrad_bn",
     "aq_conv_bwd_sums_bytes", "aq_conv_bwd", "aq_adam_step",
     "aq_bn_relu_bwd_shortcut", "aq_bn_relu_fwd_shortcut", "aq_conv_dgrad_add", "aq_synth_fwd_static",
-    "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition", "aq_tern_bwd_adam", "aq_inq_effective", "aq_bn_add_relu_fwd", "aq_bn_add_relu_bwd",
+    "aq_tern_workspace_bytes", "aq_tern_fwd", "aq_tern_bwd", "aq_inq_partition", "aq_tern_bwd_adam", "aq_inq_effective", "aq_inq_effective_sumsq", "aq_bn_add_relu_fwd", "aq_bn_add_relu_bwd",
     "aq_pkt_workspace_bytes", "aq_pkt_loss", "aq_pkt_kernel_matrix", "aq_maxpool3s2_fwd", "aq_maxpool3s2_bwd",
 )
 TERN_TWN, TERN_TTQ, TERN_INQ = 0, 1, 2
@@ -155,6 +155,8 @@ def lib():
         L.aq_inq_partition.argtypes = [vp, vp, vp, C.c_longlong, f, i, i, vp]
         L.aq_tern_bwd_adam.argtypes = [C.POINTER(AqTernSeg), i, i, C.c_double, C.c_double, C.c_double, C.c_double, f, vp, sz, vp]
         L.aq_inq_effective.argtypes = [C.POINTER(AqTernSeg), i, vp]
+        L.aq_inq_effective_sumsq.argtypes = [C.POINTER(AqTernSeg), i, vp, vp, sz, vp]
+        L.aq_inq_effective_sumsq.restype = i
         L.aq_tern_fwd.restype = L.aq_tern_bwd.restype = L.aq_inq_partition.restype = L.aq_tern_bwd_adam.restype = L.aq_inq_effective.restype = i
         L.aq_pkt_workspace_bytes.argtypes = [i, i, i]
         L.aq_pkt_workspace_bytes.restype = sz

@@ -455,6 +455,9 @@ __global__ __launch_bounds__(256) void inq_partition_kernel(float *__restrict__ 
 
 // Effective weights of INQ layers: the latent parameter where it is still trainable, the frozen level elsewhere
 // (wt = mask ? w : frozen).  The frozen values come decoded (the caller refreshes them once per INQ stage).
+// SS: also the sum of squares of the latent weights (the layer's term of the l2 regulariser, which reads the same
+// tensor), one partial per wavefront; inq_sumsq_finish_kernel adds a layer's partials in double, in ascending order.
+template <bool SS>
 __global__ __launch_bounds__(256) void inq_effective_kernel(const TernTab tab)
 {
     const int si = tern_segment(tab);
@@ -464,13 +467,66 @@ __global__ __launch_bounds__(256) void inq_effective_kernel(const TernTab tab)
     if (wt >= s.nwave) return;
     const long long e0 = (long long)wt * TERN_ELEMS_PER_WAVE;
     const float *frozen = s.dwt;  // (the table's second input stream)
+    const bool vec = ((((uintptr_t)s.w | (uintptr_t)frozen | (uintptr_t)s.wt) & 15) == 0) && (((uintptr_t)s.mask & 3) == 0);
+    float acc = 0.0f;
+    if (vec && e0 + TERN_ELEMS_PER_WAVE <= s.n) {  // whole wavefront inside the tensor: 8 + 8 + 8 loads in flight per lane
+        const tern_f4 *pw = reinterpret_cast<const tern_f4 *>(s.w + e0) + lane;
+        const tern_f4 *pf = reinterpret_cast<const tern_f4 *>(frozen + e0) + lane;
+        const unsigned *pm = reinterpret_cast<const unsigned *>(s.mask + e0) + lane;
+        tern_f4 *po = reinterpret_cast<tern_f4 *>(s.wt + e0) + lane;
+        tern_f4 a[8], f[8];
+        unsigned m[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const long long e = e0 + 256 * u + 4 * lane;
+        for (int u = 0; u < 8; ++u) {
+            a[u] = pw[64 * u];
+            f[u] = pf[64 * u];
+            m[u] = pm[64 * u];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (e + k < s.n) s.wt[e + k] = s.mask[e + k] ? s.w[e + k] : frozen[e + k];
+        for (int u = 0; u < 8; ++u) {
+            tern_f4 o;
+            o.x = (m[u] & 0xffu) ? a[u].x : f[u].x;
+            o.y = (m[u] & 0xff00u) ? a[u].y : f[u].y;
+            o.z = (m[u] & 0xff0000u) ? a[u].z : f[u].z;
+            o.w = (m[u] & 0xff000000u) ? a[u].w : f[u].w;
+            po[64 * u] = o;
+            if (SS) {
+                acc = __builtin_fmaf(a[u].x, a[u].x, acc); acc = __builtin_fmaf(a[u].y, a[u].y, acc);
+                acc = __builtin_fmaf(a[u].z, a[u].z, acc); acc = __builtin_fmaf(a[u].w, a[u].w, acc);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long e = e0 + 256 * u + 4 * lane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < s.n) {
+                    const float w = s.w[e + k];
+                    s.wt[e + k] = s.mask[e + k] ? w : frozen[e + k];
+                    if (SS) acc = __builtin_fmaf(w, w, acc);
+                }
+        }
     }
+    if (SS) {
+        acc = wave_sum(acc);
+        if (lane == 0) s.part[wt] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void inq_sumsq_finish_kernel(const TernTab tab, float *__restrict__ out)
+{
+    __shared__ double sh[256];
+    const TernSegDev &s = tab.s[blockIdx.x];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < s.nwave; k += 256) a += (double)s.part[k];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)sh[0];
 }
 
 // The quantiser's gradient rule with torch.optim.Adam's update of the latent weights applied in registers: the
@@ -787,22 +843,44 @@ int aq_inq_partition(float *W, uint8_t *mask, uint8_t *codes, long long n, float
     return check_launch("aq_inq_partition");
 }
 
-int aq_inq_effective(const aq_tern_seg *segs, int nseg, void *stream)
+static int inq_effective_common(const char *who, const aq_tern_seg *segs, int nseg, float *sumsq, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace aq;
-    if (int rc = tern_validate("aq_inq_effective", segs, nseg)) return rc;
+    if (int rc = tern_validate(who, segs, nseg)) return rc;
     for (int i = 0; i < nseg; ++i)
-        AQ_REQUIRE(segs[i].mask && segs[i].frozen && segs[i].Wt, -EFAULT, "aq_inq_effective: layer %d: mask / frozen / Wt is NULL", i);
+        AQ_REQUIRE(segs[i].mask && segs[i].frozen && segs[i].Wt, -EFAULT, "%s: layer %d: mask / frozen / Wt is NULL", who, i);
+    if (sumsq) {
+        const size_t need = tern_ws_bytes(segs, nseg);
+        AQ_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, -ENOSPC,
+                   "%s: workspace of %zu bytes (16-byte aligned) needed, %zu given", who, need, workspace_bytes);
+    }
     TernTab tab;
     aq_tern_seg tmp[TERN_MAX_SEGS];
     for (int i = 0; i < nseg; ++i) {
         tmp[i] = segs[i];
         tmp[i].dWt = segs[i].frozen;  // the kernels' second input stream
     }
-    const int blocks = tern_table(tmp, nseg, nullptr, tab);
-    AQ_REQUIRE(blocks > 0, -E2BIG, "aq_inq_effective: too many elements for one launch");
-    hipLaunchKernelGGL(inq_effective_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
-    return check_launch("aq_inq_effective");
+    const int blocks = tern_table(tmp, nseg, sumsq ? workspace : nullptr, tab);
+    AQ_REQUIRE(blocks > 0, -E2BIG, "%s: too many elements for one launch", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (sumsq) {
+        hipLaunchKernelGGL(inq_effective_kernel<true>, dim3(blocks), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(inq_sumsq_finish_kernel, dim3(nseg), dim3(256), 0, st, tab, sumsq);
+    } else {
+        hipLaunchKernelGGL(inq_effective_kernel<false>, dim3(blocks), dim3(256), 0, st, tab);
+    }
+    return check_launch(who);
+}
+
+int aq_inq_effective(const aq_tern_seg *segs, int nseg, void *stream)
+{
+    return inq_effective_common("aq_inq_effective", segs, nseg, nullptr, nullptr, 0, stream);
+}
+
+int aq_inq_effective_sumsq(const aq_tern_seg *segs, int nseg, float *sumsq, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AQ_REQUIRE(sumsq, -EFAULT, "aq_inq_effective_sumsq: NULL sumsq");
+    return inq_effective_common("aq_inq_effective_sumsq", segs, nseg, sumsq, workspace, workspace_bytes, stream);
 }
 
 int aq_tern_bwd_adam(const aq_tern_seg *segs, int nseg, int mode, double lr, double beta1, double beta2, double eps, float reg, void *workspace,

@@ -838,10 +838,12 @@ def tern_backward_adam(ws, dWts, mode, exp_avg, exp_avg_sq, steps, lr, betas=(0.
                                                wsb.data_ptr(), nbytes, _lib.stream()))
 
 
-def inq_effective(ws, masks, frozen, out=None):
-    """Effective weights of INQ layers in one launch: out[i] = where(masks[i] != 0, ws[i], frozen[i])."""
+def inq_effective(ws, masks, frozen, out=None, sumsq=False):
+    """Effective weights of INQ layers in one launch: out[i] = where(masks[i] != 0, ws[i], frozen[i]).
+    sumsq=True: -> (out, ss) with ss[i] = sum(ws[i] ** 2) from the same pass (one float per layer)."""
     n = len(ws)
     outs = out if out is not None else [torch.empty_like(w) for w in ws]
+    ss = torch.empty(n, dtype=torch.float32, device=ws[0].device) if sumsq and n else None
     for base in range(0, n, 32):
         chunk = ws[base:base + 32]
         segs = (_lib.AqTernSeg * len(chunk))()
@@ -853,8 +855,13 @@ def inq_effective(ws, masks, frozen, out=None):
             segs[i].mask = _lib.ptr(masks[j], torch.uint8, "mask")
             segs[i].frozen = _lib.ptr(frozen[j], name="frozen")
             segs[i].Wt = _lib.ptr(outs[j], name="out")
-        _lib.check(_lib.lib().aq_inq_effective(segs, len(chunk), _lib.stream()))
-    return outs
+        if ss is None:
+            _lib.check(_lib.lib().aq_inq_effective(segs, len(chunk), _lib.stream()))
+        else:
+            nbytes = _lib.lib().aq_tern_workspace_bytes(segs, len(chunk))
+            wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=ws[0].device)
+            _lib.check(_lib.lib().aq_inq_effective_sumsq(segs, len(chunk), ss[base:].data_ptr(), wsb.data_ptr(), nbytes, _lib.stream()))
+    return (outs, ss) if sumsq else outs
 
 
 def inq_partition(w, mask, tau, n1, n2, codes=None):

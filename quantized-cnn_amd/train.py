@@ -613,6 +613,10 @@ class FusedTernaryStep:
         self.dense = [p for n, p in named if id(p) not in own and p.requires_grad]
         self.reg_all = [p for n, p in named if "weight" in n]                       # the regulariser's tensors (value)
         self.dense_reg = {id(p) for n, p in named if "weight" in n and id(p) not in own}
+        # INQ: the pass that builds the effective weights also sums the squares of the latent tensors it reads
+        wid = {id(w) for w in self.ws}
+        self.reg_q = self.mode == "inq" and all(id(w) in {id(p) for p in self.reg_all} for w in self.ws)
+        self.reg_rest = [p for p in self.reg_all if id(p) not in wid]
         self.opts = make_optimizers(model, config, capturable=use_graph, fused=True)
         if self.opts.roles != ("rest",):
             raise ValueError("FusedTernaryStep: expected one optimizer over all parameters, found roles %s" % (self.opts.roles,))
@@ -663,7 +667,8 @@ class FusedTernaryStep:
         ws = [w.detach() for w in self.ws]
         if self.mode == "inq":
             fz = [l._frozen_values() for l in self.qlayers]  # persistent tensors, rewritten in place by every INQ stage
-            ops.inq_effective(ws, [l.mask for l in self.qlayers], [f[1] for f in fz], out=self.Wts)
+            # (the same pass leaves sum w^2 of every latent tensor for the regulariser: aq_sumsq then reads the other tensors only)
+            _, ss_q = ops.inq_effective(ws, [l.mask for l in self.qlayers], [f[1] for f in fz], out=self.Wts, sumsq=bool(self.reg_q))
             for l, W, slot in zip(self.qlayers, self.Wts, self.slots):
                 l._shared = (W.detach().requires_grad_(True), slot)
         else:
@@ -675,8 +680,11 @@ class FusedTernaryStep:
         prev = layers.defer_wgrad_reductions(jobs, None)
         try:
             logits = self.model.forward_body(x)
-            ss = ops.sumsq([p.detach() for p in self.reg_all]) if self.reg_all else None
-            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(getattr(self.config, "l2_reg", 0.0)), None, ss,
+            if self.mode == "inq" and self.reg_q:
+                ss = ops.sumsq([p.detach() for p in self.reg_rest]) if self.reg_rest else None
+            else:
+                ss, ss_q = (ops.sumsq([p.detach() for p in self.reg_all]) if self.reg_all else None), None
+            vals, dlogits = ops.ce_loss(logits.detach().contiguous(), y, float(getattr(self.config, "l2_reg", 0.0)), ss_q, ss,
                                         grad_scale=1.0 / self.dp.world if self._exchange else 1.0)
             logits.backward(dlogits)
         finally:

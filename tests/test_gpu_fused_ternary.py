@@ -20,6 +20,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
+    import quantized_cnn_amd.ops as ops
     import quantized_cnn_amd.ternary as T
     from quantized_cnn_amd.resnet18 import ResNet18
     from quantized_cnn_amd.train import FusedTernaryStep, TrainStep
@@ -170,3 +171,26 @@ def test_cross_entropy_kernels_equal_torch(N, C):
     bad = y.clone()
     bad[0] = C
     assert bool(torch.isnan(ops.ce_loss(logits.detach(), bad, need_grad=False)[0][0]))
+
+
+@pytest.mark.parametrize("offset", [0, 1, 3])
+def test_inq_effective_weights_and_sum_of_squares(offset):
+    """aq_inq_effective / aq_inq_effective_sumsq: where(mask, w, frozen) bit for bit, on whole 16-byte aligned wavefront
+    runs (the 16-byte path), on ragged tails and on views that are only 4-byte aligned (offset: the scalar path); the
+    sums of squares of the latent tensors from the same pass against a float64 sum (parity unpinned: no reference INQ)."""
+    g = torch.Generator(device=DEV).manual_seed(11 + offset)
+    sizes = [5, 2048, 2049, 64 * 64 * 9, 300001]
+    bufs = [torch.randn(n + 4, device=DEV, generator=g) for n in sizes]
+    ws = [b[offset:offset + n] for b, n in zip(bufs, sizes)]
+    masks = [(torch.rand(n + 4, device=DEV, generator=g) < 0.5).to(torch.uint8)[offset:offset + n] for n in sizes]
+    frozen = [torch.randn(n + 4, device=DEV, generator=g)[offset:offset + n] for n in sizes]
+    outs = [torch.full((n + 4,), float("nan"), device=DEV)[offset:offset + n] for n in sizes]
+    plain = ops.inq_effective(ws, masks, frozen)
+    got, ss = ops.inq_effective(ws, masks, frozen, out=outs, sumsq=True)
+    for w, m, f, a, b in zip(ws, masks, frozen, plain, got):
+        want = torch.where(m != 0, w, f)
+        assert torch.equal(a, want) and torch.equal(b, want)
+    ref = torch.stack([w.double().pow(2).sum() for w in ws])
+    assert float(((ss.double() - ref).abs() / ref).max()) <= 2e-6
+    _, ss2 = ops.inq_effective(ws, masks, frozen, out=outs, sumsq=True)
+    assert torch.equal(ss, ss2)
