@@ -1746,6 +1746,11 @@ static int launch_gemm_impl(ConvArgs &a, int N, hipStream_t st, const char *who,
     if (dry) return 0;
     AQ_REQUIRE(!a.bn_on, -ENOTSUP, "%s: no kernel with fused input normalisation for this shape", who);
     AQ_REQUIRE(!a.stat_part && !a.bwd_part, -ENOTSUP, "%s: no statistics epilogue for this shape", who);
+    if (MODE != MODE_FWD_CODES) {  // stride 1, at least 64 channels either side: the minimal-filtering form (2.25 times less matrix work)
+        bool taken = false;
+        const int rc = MODE == MODE_DGRAD ? aq_wino_launch_dgrad(a, N, st, who, &taken) : aq_wino_launch_fwd(a, N, st, who, &taken);
+        if (taken) return rc;
+    }
     {
         bool taken = false;
         const int rc = launch_c3<MODE>(a, N, st, who, &taken);

@@ -149,3 +149,9 @@ struct WgStemPlan {
 WgStemPlan wgrad_stem_plan(const float *dy, int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad);
 int wgrad_stem_launch(const float *x, const float *dy, float *part, int N, int Cin, int H, int Wd, int Cout, int ks, int stride, int pad,
                       hipStream_t st);
+
+// ---- aq_conv_wino.hip -----------------------------------------------------------------------------------------
+// forward / input gradient of 3x3, stride 1, padding 1 layers with at least 64 channels in and out (multiples of 16) by
+// the F(2x2, 3x3) minimal-filtering form; *taken = false: not one of its shapes, nothing launched
+int aq_wino_launch_fwd(const aq::ConvArgs &a, int N, hipStream_t st, const char *who, bool *taken);
+int aq_wino_launch_dgrad(const aq::ConvArgs &a, int N, hipStream_t st, const char *who, bool *taken);

@@ -22,7 +22,11 @@ SHAPES = [  # cin, cout, ks, stride, pad, H, W, N
     (3, 64, 7, 2, 3, 100, 120, 2),     # stem kernels: rows of 60 output pixels (four pixel tiles, the last one ragged), 50 rows
     (3, 128, 7, 2, 3, 50, 46, 3),      # ... two groups of 64 output channels; 23 pixels per row (no multiple of 4: general weight gradient)
     (3, 64, 7, 2, 2, 33, 37, 2),       # ... padding 2, odd sizes
-    (64, 64, 3, 1, 1, 56, 56, 1),      # layer1 (fits the tuned kernels)
+    (64, 64, 3, 1, 1, 56, 56, 1),      # layer1: stride 1, padding 1, >= 64 channels either side run in the F(2x2, 3x3) form
+    (64, 64, 3, 1, 1, 13, 9, 2),       # ... odd sizes: the last tile row / column owns one pixel row / column only
+    (80, 96, 3, 1, 1, 7, 7, 3),        # ... a ragged group of output channels (96 = 64 + 32), 16 tiles covering 8 x 8 pixels
+    (64, 64, 3, 1, 1, 5, 31, 1),       # ... wide and flat: blocks of 2 x 8 tiles
+    (128, 64, 3, 1, 1, 1, 1, 4),       # ... a single pixel
     (64, 128, 3, 2, 1, 56, 56, 1),     # layer2.0.conv1
     (64, 128, 1, 2, 0, 56, 56, 2),     # layer2.0 projection
     (128, 128, 3, 1, 1, 28, 28, 2),
@@ -74,7 +78,10 @@ def test_general_conv_forward_dgrad_wgrad_vs_oracle(shape):
     near(ops.conv_forward(xd, Wdv, stride, res=cu(res), pad=pad).cpu().numpy(), y_ref + res, "y + res")
     dy = rs.standard_normal(y_ref.shape).astype(np.float32)
     dyd = cu(dy)
-    near(ops.conv_dgrad(dyd, Wdv, x.shape, stride, pad=pad).cpu().numpy(), O.conv_dgrad(dy, W, x.shape, stride, pad), "dx")
+    dx_ref = O.conv_dgrad(dy, W, x.shape, stride, pad)
+    near(ops.conv_dgrad(dyd, Wdv, x.shape, stride, pad=pad).cpu().numpy(), dx_ref, "dx")
+    xres = rs.standard_normal(x.shape).astype(np.float32)
+    near(ops.conv_dgrad(dyd, Wdv, x.shape, stride, res=cu(xres), pad=pad).cpu().numpy(), dx_ref + xres, "dx + res")
     dW = ops.conv_wgrad(xd, dyd, stride, ks=ks, pad=pad)
     assert tuple(dW.shape) == W.shape
     near(dW.cpu().numpy(), O.conv_wgrad(x, dy, ks, stride, pad), "dW")
