@@ -217,7 +217,7 @@ def kernel_rooflines(quick):
             if name == "conv_dgrad" and cin == 3:
                 continue  # the stem's input needs no gradient
             t = event_time(fn, 5, 2)
-            more.append({"bound": "mfma", "kernel": "%s %d->%d k%d s%d %dx%d N=%d (ResNet-18 shape, general kernels; no reference model)" % (
+            more.append({"bound": "mfma", "kernel": "%s %d->%d k%d s%d %dx%d N=%d (ResNet-18 shape: stem, F(2x2,3x3), many-channel and 1x1 kernels of aq_conv_*.hip; no reference model)" % (
                 name, cin, cout, ks, s, H, H, B18), "achieved": round(fl / t / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(fl / t / 1e12 / FP32_MATRIX_PEAK_TF, 4), "avg_launch_us": round(t * 1e6, 2)})
     def graph_time(fn, reps=20):
