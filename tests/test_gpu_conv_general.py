@@ -157,3 +157,21 @@ def test_one_by_one_gemm_forward_and_dgrad_vs_oracle(shape):
         assert np.all(dx[:, :, mask] == 0.0)
     xres = rs.standard_normal(x.shape).astype(np.float32)
     near(ops.conv_dgrad(cu(dy), Wdv, x.shape, stride, res=cu(xres), pad=0).cpu().numpy(), dx_ref + xres, "dx + res")
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 56, 4), (256, 256, 14, 4), (512, 512, 7, 4)], ids=lambda s: "x".join(map(str, s)))
+def test_minimal_filtering_form_on_positive_activations(shape):
+    """The F(2x2, 3x3) kernel subtracts neighbouring inputs before it multiplies: on activations as a network feeds them
+    (after a ReLU: positive, far from zero mean) its forward and input-gradient results stay within 5e-6 of the result's
+    scale of a float64 convolution (measured 4e-7 .. 1.1e-6; the stock fp32 operator: 4e-7 .. 7e-7)."""
+    cin, cout, H, N = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(N, cin, H, H, device=DEV, generator=g).abs() + 3.0
+    W = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5
+    y64 = torch.nn.functional.conv2d(x.double(), W.double(), padding=1)
+    y = ops.conv_forward(x, W, 1, pad=1)
+    assert (y.double() - y64).abs().max().item() <= 5e-6 * y64.abs().max().item()
+    dy = torch.randn(y.shape, device=DEV, generator=g).abs() + 1.0
+    dx64 = torch.nn.functional.conv_transpose2d(dy.double(), W.double(), padding=1)
+    dx = ops.conv_dgrad(dy, W, x.shape, 1, pad=1)
+    assert (dx.double() - dx64).abs().max().item() <= 5e-6 * dx64.abs().max().item()
